@@ -1,0 +1,452 @@
+"""TEST INFRASTRUCTURE ONLY -- functional CPU restatement of the JSPSR hot path.
+
+Written against a flat ``state_dict`` (the reference's key names) so it
+shares no module code with either the reference or the product package.  Every function
+cites the reference lines it restates (paths relative to /root/reference).
+
+Pinned by tests/golden/*.npz, which were produced by the reference's own modules
+(oracle/gen_golden.py).  Works in fp32 or fp64; differentiable through torch autograd, and
+``propagate_analytic_backward`` gives the closed-form gradients independently of autograd.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+# --------------------------------------------------------------------------------------
+# propagation step (models/components/spn.py:99-118 + torchvision 0.16 deform_conv2d)
+# --------------------------------------------------------------------------------------
+
+
+def _corner(dem: torch.Tensor, yy: torch.Tensor, xx: torch.Tensor) -> torch.Tensor:
+    """dem (B,1,H,W) read at integer (yy,xx) of shape (B,K,H,W); 0 outside the raster."""
+    B, _, H, W = dem.shape
+    ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+    idx = yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)
+    flat = dem.reshape(B, 1, H * W).expand(B, idx.shape[1], H * W)
+    val = torch.gather(flat, 2, idx.reshape(B, idx.shape[1], H * W)).reshape(idx.shape)
+    return torch.where(ok, val, torch.zeros((), dtype=dem.dtype))
+
+
+def sample_taps(dem: torch.Tensor, offset: torch.Tensor) -> torch.Tensor:
+    """Formulation A (explicit 4-corner gather) of the deformable 3x3 sampler.
+
+    torchvision semantics: offset channel 2k = dy, 2k+1 = dx of tap k
+    (row-major over the window); position p = (y-1+k//3+dy, x-1+k%3+dx); bilinear with
+    out-of-raster corners contributing 0 and the whole sample 0 when p_y<=-1, p_y>=H,
+    p_x<=-1 or p_x>=W.  Returns S of shape (B,9,H,W).
+    """
+    B, _, H, W = dem.shape
+    dt = dem.dtype
+    ys = torch.arange(H, dtype=dt).view(1, 1, H, 1)
+    xs = torch.arange(W, dtype=dt).view(1, 1, 1, W)
+    ky = torch.tensor([k // 3 - 1 for k in range(9)], dtype=dt).view(1, 9, 1, 1)
+    kx = torch.tensor([k % 3 - 1 for k in range(9)], dtype=dt).view(1, 9, 1, 1)
+    off = offset.reshape(B, 9, 2, H, W)
+    py = ys + ky + off[:, :, 0]
+    px = xs + kx + off[:, :, 1]
+    y0f = torch.floor(py)
+    x0f = torch.floor(px)
+    ly = py - y0f
+    lx = px - x0f
+    hy = 1 - ly
+    hx = 1 - lx
+    y0 = y0f.long()
+    x0 = x0f.long()
+    v00 = _corner(dem, y0, x0)
+    v01 = _corner(dem, y0, x0 + 1)
+    v10 = _corner(dem, y0 + 1, x0)
+    v11 = _corner(dem, y0 + 1, x0 + 1)
+    val = hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11
+    inside = (py > -1) & (py < H) & (px > -1) & (px < W)
+    return torch.where(inside, val, torch.zeros((), dtype=dt))
+
+
+def propagate(
+    dem: torch.Tensor,
+    weight: torch.Tensor,
+    offset: torch.Tensor,
+    w: torch.Tensor,
+    b: torch.Tensor,
+    scale: float = 1.0,
+    residual: bool = True,
+) -> torch.Tensor:
+    """PostProcessor.forward, models/components/spn.py:99-118.
+
+    dem (B,1,H,W), weight (B,9,H,W), offset (B,18,H,W), w (1,1,3,3), b (1,) -> (B,1,H,W).
+    """
+    if residual:
+        m = weight - weight.mean(1, keepdim=True)  # spn.py:100-101
+    else:
+        m = weight / weight.sum(1, keepdim=True)  # spn.py:103
+    S = sample_taps(dem, offset)
+    out = (w.reshape(1, 9, 1, 1) * m * S).sum(1, keepdim=True) + b.reshape(1, 1, 1, 1)
+    if residual:
+        out = out + scale * dem  # spn.py:116-117
+    return out
+
+
+def propagate_analytic_backward(dem, weight, offset, w, b, grad_out):
+    """Closed-form gradients of ``propagate`` (residual=True) -- SURVEY.md section 8a row a10.
+
+    Returns (grad_weight, grad_offset, grad_w, grad_b).  Coordinate derivative follows
+    torchvision's get_coordinate_weight: per-corner validity only (no 'inside' gate).
+    """
+    B, _, H, W = dem.shape
+    dt = dem.dtype
+    ys = torch.arange(H, dtype=dt).view(1, 1, H, 1)
+    xs = torch.arange(W, dtype=dt).view(1, 1, 1, W)
+    ky = torch.tensor([k // 3 - 1 for k in range(9)], dtype=dt).view(1, 9, 1, 1)
+    kx = torch.tensor([k % 3 - 1 for k in range(9)], dtype=dt).view(1, 9, 1, 1)
+    off = offset.reshape(B, 9, 2, H, W)
+    py = ys + ky + off[:, :, 0]
+    px = xs + kx + off[:, :, 1]
+    y0f, x0f = torch.floor(py), torch.floor(px)
+    ly, lx = py - y0f, px - x0f
+    hy, hx = 1 - ly, 1 - lx
+    y0, x0 = y0f.long(), x0f.long()
+    v00 = _corner(dem, y0, x0)
+    v01 = _corner(dem, y0, x0 + 1)
+    v10 = _corner(dem, y0 + 1, x0)
+    v11 = _corner(dem, y0 + 1, x0 + 1)
+    inside = ((py > -1) & (py < H) & (px > -1) & (px < W)).to(dt)
+    S = inside * (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11)
+    dSdy = hx * (v10 - v00) + lx * (v11 - v01)
+    dSdx = hy * (v01 - v00) + ly * (v11 - v10)
+    m = weight - weight.mean(1, keepdim=True)
+    wk = w.reshape(1, 9, 1, 1)
+    g = grad_out
+    gm = g * wk * S
+    grad_weight = gm - gm.mean(1, keepdim=True)
+    coef = g * wk * m
+    grad_offset = torch.stack((coef * dSdy, coef * dSdx), 2).reshape(B, 18, H, W)
+    grad_w = (g * m * S).sum((0, 2, 3)).reshape(1, 1, 3, 3)
+    grad_b = g.sum().reshape(1)
+    return grad_weight, grad_offset, grad_w, grad_b
+
+
+# --------------------------------------------------------------------------------------
+# building blocks (models/components/basics.py, resnet_cbam.py:36-53)
+# --------------------------------------------------------------------------------------
+
+
+class Ctx:
+    """Carries the flat state dict and the train/eval switch through the functional graph."""
+
+    def __init__(self, sd: SD, training: bool, momentum: float = 0.1, eps: float = 1e-5):
+        self.sd = sd
+        self.training = training
+        self.momentum = momentum
+        self.eps = eps
+
+    def __getitem__(self, k):
+        return self.sd[k]
+
+    def get(self, k):
+        return self.sd.get(k)
+
+
+def batch_norm(c: Ctx, x, p):
+    """nn.BatchNorm2d (basics.py:49,81,105,108); updates running stats in train mode."""
+    nbt = c.get(p + ".num_batches_tracked")
+    if c.training and nbt is not None:
+        nbt += 1
+    return F.batch_norm(
+        x,
+        c[p + ".running_mean"],
+        c[p + ".running_var"],
+        c[p + ".weight"],
+        c[p + ".bias"],
+        c.training,
+        c.momentum,
+        c.eps,
+    )
+
+
+def channel_attention(c: Ctx, x, p):
+    """ChannelAttention.forward, resnet_cbam.py:49-53 (shared bias-free 1x1 MLP)."""
+    w1, w2 = c[p + ".fc.0.weight"], c[p + ".fc.2.weight"]
+
+    def mlp(v):
+        return F.conv2d(F.relu(F.conv2d(v, w1)), w2)
+
+    avg = x.mean((2, 3), keepdim=True)
+    mx = x.amax((2, 3), keepdim=True)
+    return torch.sigmoid(mlp(avg) + mlp(mx))
+
+
+def basic2d(c: Ctx, x, p, k=3, bn=True, relu=True, camb=False):
+    """Basic2d.forward, basics.py:55-60 (conv has bias iff bn is False, :36)."""
+    if camb:
+        x = channel_attention(c, x, p + ".camb") * x
+    y = F.conv2d(x, c[p + ".conv.0.weight"], c.get(p + ".conv.0.bias"), 1, k // 2)
+    if bn:
+        y = batch_norm(c, y, p + ".conv.bn")
+    return F.relu(y) if relu else y
+
+
+def basic2d_trans(c: Ctx, x, p):
+    """Basic2dTrans.forward, basics.py:63-85: Basic2d(camb) -> ConvT k3 s2 p1 op1 -> BN -> ReLU."""
+    y = basic2d(c, x, p + ".dconv.0", 3, bn=True, relu=True, camb=True)
+    y = F.conv_transpose2d(y, c[p + ".dconv.1.weight"], None, 2, 1, 1)
+    return F.relu(batch_norm(c, y, p + ".dconv.bn"))
+
+
+def basic_block(c: Ctx, x, p, stride=1, act=True, scale=1.0):
+    """BasicBlock.forward, basics.py:111-123."""
+    y = F.conv2d(x, c[p + ".conv1.weight"], None, stride, 1)
+    y = F.relu(batch_norm(c, y, p + ".bn1"))
+    y = F.conv2d(y, c[p + ".conv2.weight"], None, 1, 1)
+    y = batch_norm(c, y, p + ".bn2")
+    if (p + ".downsample.0.weight") in c.sd:
+        r = F.conv2d(x, c[p + ".downsample.0.weight"], None, stride, 0)
+        r = batch_norm(c, r, p + ".downsample.1")
+    else:
+        r = x
+    y = y * scale + r
+    return F.relu(y) if act else y
+
+
+def layer(c: Ctx, x, p, n_blocks, stride):
+    """nn.Sequential of BasicBlocks built by _make_layer, JSPSR.py:382-492."""
+    for i in range(n_blocks):
+        x = basic_block(c, x, f"{p}.{i}", stride if i == 0 else 1)
+    return x
+
+
+def generator(c: Ctx, dem, ctx_feat, p="generator"):
+    """Generator.forward, spn.py:54-75 -> weight (B,9,H,W) in (0,1), offset (B,18,H,W)."""
+    B, _, H, W = dem.shape
+    d = basic2d(c, basic2d(c, dem, p + ".convd1", bn=False), p + ".convd2", bn=False)
+    f = basic2d(c, basic2d(c, ctx_feat, p + ".convf1", bn=False), p + ".convf2", bn=False)
+    x = basic2d(c, torch.cat((d, f), 1), p + ".conv", bn=False)
+    x = basic_block(c, x, p + ".block")
+    weight = torch.sigmoid(
+        F.conv2d(x, c[p + ".conv_weight.0.weight"], c[p + ".conv_weight.0.bias"])
+    )
+    off16 = F.conv2d(x, c[p + ".conv_offset.conv.0.weight"], c[p + ".conv_offset.conv.0.bias"])
+    zero = torch.zeros(B, 2, H, W, dtype=off16.dtype)
+    offset = torch.cat((off16[:, :8], zero, off16[:, 8:]), 1)  # centre tap: spn.py:70-73
+    return weight, offset
+
+
+# --------------------------------------------------------------------------------------
+# the model (models/JSPSR.py:208-380)
+# --------------------------------------------------------------------------------------
+
+
+def jspsr_forward(
+    sd: SD,
+    inputs: Sequence[torch.Tensor],
+    training: bool,
+    layers: Sequence[int] = (2, 2, 2, 2),
+    spn_scale: float = 1.0,
+    return_aux: bool = False,
+):
+    """JSPSR Model.forward for inputs [dem, img] or [dem, img, msk] (JSPSR.py:208-380).
+
+    Branch set is inferred from the state dict (conv_img / conv_aux present or not).
+    """
+    c = Ctx(sd, training)
+    has_img = "conv_img.conv.0.weight" in sd
+    has_aux = "conv_aux.conv.0.weight" in sd
+    if len(inputs) != 1 + int(has_img) + int(has_aux):
+        raise NotImplementedError  # parse_input, JSPSR.py:519-550
+    dem = inputs[0]
+    feats = {"dem": basic2d(c, dem, "conv_dem", 5, bn=False)}  # JSPSR.py:66-68,220
+    if has_img:
+        feats["img"] = basic2d(c, inputs[1], "conv_img", 5, bn=True)  # :70,221
+    if has_aux:
+        feats["aux"] = basic2d(c, inputs[-1], "conv_aux", 5, bn=False)  # :75-77,222
+    order = [k for k in ("dem", "img", "aux") if k in feats]
+    fuse = []
+    for stage in range(4):  # JSPSR.py:230-352
+        stride = 1 if stage == 0 else 2
+        nxt = {}
+        for br in order:
+            src = feats[br]
+            if br == "dem" and stage > 0:
+                src = fuse[-1]  # dem branch consumes the fused tensor, :261,292,323
+            nxt[br] = layer(c, src, f"layer{stage + 1}_{br}", layers[stage], stride)
+        feats = nxt
+        fuse.append(torch.cat([feats[b] for b in order], 1))  # Guide(cat_only), basics.py:134
+    x = fuse[3]
+    for name, skip in (("layer3d", fuse[2]), ("layer2d", fuse[1]), ("layer1d", fuse[0])):
+        x = torch.cat((basic2d_trans(c, x, name), skip), 1)  # :354-368
+    c0 = basic2d(c, x, "conv0", 3, bn=True, relu=True, camb=True)  # :369
+    dem_d = dem.detach()  # :372
+    weight, offset = generator(c, dem_d, c0)
+    out = propagate(dem_d, weight, offset, sd["postprocessor.w"], sd["postprocessor.b"], spn_scale)
+    if return_aux:
+        return out, {"c0": c0, "weight": weight, "offset": offset}
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# parameter sets (JSPSR.py:10-206 shapes, :494-517 init)
+# --------------------------------------------------------------------------------------
+
+
+def jspsr_param_shapes(in_channels: dict, num_feature=32, layers=(2, 2, 2, 2)) -> Dict[str, tuple]:
+    """Shapes of every state-dict entry of models.JSPSR.Model, in the reference's order."""
+    nf = num_feature
+    has_img = "image" in in_channels
+    aux_key = next((k for k in ("mask", "canopy", "coord") if k in in_channels), None)
+    nb = 1 + int(has_img) + int(aux_key is not None)
+    out: Dict[str, tuple] = {}
+
+    def conv(name, co, ci, k, bias):
+        out[name + ".weight"] = (co, ci, k, k)
+        if bias:
+            out[name + ".bias"] = (co,)
+
+    def bn(name, ch):
+        out[name + ".weight"] = (ch,)
+        out[name + ".bias"] = (ch,)
+        out[name + ".running_mean"] = (ch,)
+        out[name + ".running_var"] = (ch,)
+        out[name + ".num_batches_tracked"] = ()
+
+    def b2d(name, ci, co, k, use_bn, camb=False):
+        if camb:
+            out[name + ".camb.fc.0.weight"] = (ci // 16, ci, 1, 1)
+            out[name + ".camb.fc.2.weight"] = (ci, ci // 16, 1, 1)
+        conv(name + ".conv.0", co, ci, k, not use_bn)
+        if use_bn:
+            bn(name + ".conv.bn", co)
+
+    def block(name, ci, co, down):
+        conv(name + ".conv1", co, ci, 3, False)
+        bn(name + ".bn1", co)
+        conv(name + ".conv2", co, co, 3, False)
+        bn(name + ".bn2", co)
+        if down:
+            conv(name + ".downsample.0", co, ci, 1, False)
+            bn(name + ".downsample.1", co)
+
+    branches = ["dem"] + (["img"] if has_img else []) + (["aux"] if aux_key else [])
+    b2d("conv_dem", in_channels["lr_dem"], nf, 5, False)
+    if has_img:
+        b2d("conv_img", in_channels["image"], nf, 5, True)
+    if aux_key:
+        b2d("conv_aux", in_channels[aux_key], nf, 5, False)
+    inpl = nf
+    for s in range(4):
+        planes = nf * 2 * (2**s)
+        for br in branches:
+            ci = inpl * (nb if (br == "dem" and s > 0) else 1)
+            for i in range(layers[s]):
+                block(f"layer{s + 1}_{br}.{i}", ci if i == 0 else planes, planes, i == 0)
+        inpl = planes
+    for name, ci, co in (
+        ("layer3d", nf * 16 * nb, nf * 8),
+        ("layer2d", nf * 8 + nf * 8 * nb, nf * 4),
+        ("layer1d", nf * 4 + nf * 4 * nb, nf * 2),
+    ):
+        b2d(name + ".dconv.0", ci, co, 3, True, camb=True)
+        out[name + ".dconv.1.weight"] = (co, co, 3, 3)
+        bn(name + ".dconv.bn", co)
+    b2d("conv0", nf * 2 + nf * 2 * nb, nf * 2, 3, True, camb=True)
+    bc = nf
+    g = "generator"
+    b2d(g + ".convd1", 1, bc * 2, 3, False)
+    b2d(g + ".convd2", bc * 2, bc * 2, 3, False)
+    b2d(g + ".convf1", nf * 2, bc * 2, 3, False)
+    b2d(g + ".convf2", bc * 2, bc * 2, 3, False)
+    b2d(g + ".conv", bc * 4, bc * 4, 3, False)
+    block(g + ".block", bc * 4, bc * 4, False)
+    conv(g + ".conv_weight.0", 9, bc * 4, 1, True)
+    conv(g + ".conv_offset.conv.0", 16, bc * 4, 1, True)
+    out["postprocessor.w"] = (1, 1, 3, 3)
+    out["postprocessor.b"] = (1,)
+    return out
+
+
+def make_state_dict(shapes: Dict[str, tuple], seed: int, dtype=torch.float32) -> SD:
+    """Deterministic parameter set with the reference's init *distribution*
+    (JSPSR.py:494-517: truncated normal +-2 sigma, sigma = sqrt(2.6/(k*k*C_in)); bias 0; BN 1/0)
+    drawn from a seeded torch CPU generator so it can be regenerated on any box without scipy.
+    BN affine/running stats and conv biases are perturbed a little so parity tests see them.
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+    for k, shp in shapes.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif len(shp) == 4 and k != "postprocessor.w":
+            n = shp[1] * shp[2] * shp[3]
+            if ".dconv.1." in k:  # ConvTranspose2d: in_channels is dim 0
+                n = shp[0] * shp[2] * shp[3]
+            std = math.sqrt(2.6 / n)
+            t = torch.empty(shp, dtype=torch.float64)
+            torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std, generator=g)
+            sd[k] = t.to(dtype)
+        elif k == "postprocessor.w":
+            sd[k] = (1 + 0.2 * torch.randn(shp, generator=g, dtype=torch.float64)).to(dtype)
+        elif k == "postprocessor.b":
+            sd[k] = (0.01 * torch.randn(shp, generator=g, dtype=torch.float64)).to(dtype)
+        elif k.endswith("running_var"):
+            sd[k] = (1 + 0.2 * torch.rand(shp, generator=g, dtype=torch.float64)).to(dtype)
+        elif k.endswith("running_mean"):
+            sd[k] = (0.1 * torch.randn(shp, generator=g, dtype=torch.float64)).to(dtype)
+        elif ".bn" in k or ".downsample.1." in k:
+            base = 1.0 if k.endswith("weight") else 0.0
+            sd[k] = (base + 0.1 * torch.randn(shp, generator=g, dtype=torch.float64)).to(dtype)
+        else:  # conv bias
+            sd[k] = (0.05 * torch.randn(shp, generator=g, dtype=torch.float64)).to(dtype)
+    return sd
+
+
+def synthetic_batch(B, H, W, with_mask: bool, seed=0, dtype=torch.float32):
+    """Synthetic inputs of SURVEY.md section 8d: smooth DEM in the log-min-max range
+    (data/data_utils.py:289-312), uint8 image /255 (:225-227), block one-hot mask with channel
+    i scaled by (i+1)/16 (:262-265).  Returns (inputs list, target)."""
+    g = torch.Generator().manual_seed(seed)
+    z = torch.zeros(B, 1, H, W, dtype=torch.float64)
+    for o in range(4):
+        n = max(2, min(H, W) // (32 >> o) if (32 >> o) > 0 else 2)
+        noise = torch.randn(B, 1, n, n, generator=g, dtype=torch.float64)
+        z = z + F.interpolate(noise, size=(H, W), mode="bilinear", align_corners=True) / (2**o)
+    z = (z - z.amin((2, 3), keepdim=True)) / (z.amax((2, 3), keepdim=True) - z.amin((2, 3), keepdim=True) + 1e-12)
+    z = z * 120.0
+    lr = torch.log(z + 80.0) / math.log(1009.0)
+    hr = torch.log((z + torch.randn(z.shape, generator=g, dtype=torch.float64)).clamp_min(-79.0) + 80.0) / math.log(1009.0)
+    img = torch.randint(0, 256, (B, 3, H, W), generator=g).to(torch.float64) / 255.0
+    inputs = [lr.to(dtype), img.to(dtype)]
+    if with_mask:
+        bs = 32
+        cls = torch.randint(0, 15, (B, (H + bs - 1) // bs, (W + bs - 1) // bs), generator=g)
+        cls = cls.repeat_interleave(bs, 1).repeat_interleave(bs, 2)[:, :H, :W]
+        msk = F.one_hot(cls, 15).permute(0, 3, 1, 2).to(torch.float64)
+        msk = msk * ((torch.arange(15, dtype=torch.float64) + 1) / 16).view(1, 15, 1, 1)
+        inputs.append(msk.to(dtype))
+    return inputs, hr.to(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# loss (losses/loss_schemes.py:55-72 with configs/*.yml:67-70: L1 1, L2 1, Grad 0.1)
+# --------------------------------------------------------------------------------------
+
+
+def sobel_gradient(x: torch.Tensor) -> torch.Tensor:
+    """kornia.filters.spatial_gradient(mode='sobel', order=1, normalized=True) restated:
+    replicate padding, kernels [[-1,0,1],[-2,0,2],[-1,0,1]]/8 and its transpose (SURVEY 8c:
+    recalled from kornia's public source; unpinned).  (B,C,H,W) -> (B,C,2,H,W)."""
+    B, C, H, W = x.shape
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], dtype=x.dtype) / 8.0
+    k = torch.stack((kx, kx.t())).unsqueeze(1)
+    xp = F.pad(x.reshape(B * C, 1, H, W), (1, 1, 1, 1), mode="replicate")
+    return F.conv2d(xp, k).reshape(B, C, 2, H, W)
+
+
+def multi_loss(pred, gt, w_l1=1.0, w_l2=1.0, w_grad=0.1):
+    """MultiLoss(L1, L2, Grad): loss_schemes.py:61-72, loss_functions.py:171-185."""
+    l1 = (pred - gt).abs().mean()
+    l2 = ((pred - gt) ** 2).mean()
+    ge = (sobel_gradient(pred) - sobel_gradient(gt)).abs().mean()
+    return {"L1": l1, "L2": l2, "Grad": ge, "Total": w_l1 * l1 + w_l2 * l2 + w_grad * ge}
