@@ -1,0 +1,72 @@
+"""ctypes binding of lib/libjspsr_hip.so (C ABI: include/jspsr_hip.h).
+
+The library is loaded lazily and loudly: a missing or stale .so is an error, never a fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libjspsr_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_f = ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/jspsr_hip.h declares
+SIGNATURES = {
+    "jspsr_abi_version": (c_i, []),
+    "jspsr_last_error": (ctypes.c_char_p, []),
+    "jspsr_prop_forward_f32": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
+    "jspsr_prop_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "jspsr_prop_backward_f32": (c_i, [c_p] * 4 + [c_i] + [c_p] * 6 + [c_i, c_i, c_i, c_p]),
+}
+
+
+class JspsrHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source under csrc/ for gfx950 into lib/libjspsr_hip.so (hipcc)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(SO_PATH):
+            raise JspsrHipError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). jspsr_amd has no fallback path."
+            )
+        lib = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        v = lib.jspsr_abi_version()
+        if v != ABI_VERSION:
+            raise JspsrHipError(f"libjspsr_hip.so ABI {v} != binding ABI {ABI_VERSION}: rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().jspsr_last_error().decode(errors="replace")
+        raise JspsrHipError(f"{what} failed (code {code}): {msg}")

@@ -1,0 +1,29 @@
+// Shared host-side helpers of libjspsr_hip.so (gfx950 only; no other targets, no shims).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/jspsr_hip.h"
+
+namespace jspsr {
+
+// Per-thread error text behind jspsr_last_error().
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+// Workgroups b and b+8 share an XCD (private 4 MiB L2) under the observed round-robin dispatch.
+// Bijective remap that hands every XCD one contiguous run of logical tile ids, so that
+// neighbouring tiles (which share halo rows / operand panels) hit the same L2.  Speed only.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblk) {
+  if (nblk < 16) return bid;
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, local = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+}  // namespace jspsr
