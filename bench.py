@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixel/s of one JSPSR training step on 512x512 DEM tiles (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE config 3 / 4): JSPSR image+mask guided (jspsr_r8_img_msk.yml architecture,
+num_feature 32, layers 2-2-2-2, 43.87 M parameters, reference init), 8 tiles of 512x512 per GPU,
+synthetic inputs.  One step = zero_grad -> model(*inputs) -> L1 + L2 +
+0.1*Sobel-L1 -> backward -> gradient all-reduce (N > 1) -> AdamW step, i.e. the body of the
+reference's train_one_epoch (train/train_utils.py:210-219).  Weak scaling: 8 tiles per GPU.
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (K1, the HBM-bound propagation kernels,
+timed live with events on the launch stream; algorithmic bytes per SURVEY.md section 8d) and, at
+N = 1, "cpu_baseline" (the oracle's CPU restatement timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+IN_CHANNELS = {"COP30": 1, "image": 3, "mask": 15, "lr_dem": 1}  # configs/jspsr_r8_img_msk.yml:33-38
+TILE = 512
+TILES_PER_GPU = 8
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synthetic_batch(B, H, W, device, seed):
+    """SURVEY.md section 8d inputs, generated on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    z = torch.zeros(B, 1, H, W, device=device)
+    for o, n in enumerate((16, 32, 64, 128)):
+        noise = torch.randn(B, 1, n, n, device=device, generator=g)
+        z = z + torch.nn.functional.interpolate(noise, size=(H, W), mode="bilinear", align_corners=True) / (2**o)
+    lo, hi = z.amin((2, 3), keepdim=True), z.amax((2, 3), keepdim=True)
+    z = (z - lo) / (hi - lo + 1e-12) * 120.0
+    lr = torch.log(z + 80.0) / float(np.log(1009.0))
+    hr = torch.log((z + torch.randn(z.shape, device=device, generator=g)).clamp_min(-79.0) + 80.0) / float(np.log(1009.0))
+    img = torch.randint(0, 256, (B, 3, H, W), device=device, generator=g).float() / 255.0
+    cls = torch.randint(0, 15, (B, H // 32, W // 32), device=device, generator=g)
+    cls = cls.repeat_interleave(32, 1).repeat_interleave(32, 2)
+    msk = torch.nn.functional.one_hot(cls, 15).permute(0, 3, 1, 2).float()
+    msk = msk * ((torch.arange(15, device=device).float() + 1) / 16).view(1, 15, 1, 1)
+    return [lr.contiguous(), img.contiguous(), msk.contiguous()], hr.contiguous()
+
+
+def time_k1(model, inputs, iters=20):
+    """Roofline of K1 on this batch's real affinities/offsets (events on the launch stream)."""
+    from jspsr_amd import ops
+    dem = inputs[0]
+    B, _, H, W = dem.shape
+    g = torch.Generator(device=dem.device).manual_seed(1)
+    # several operand sets: defeat the 256 MiB Infinity Cache so HBM is what is measured
+    nset = 4
+    sets = []
+    for _ in range(nset):
+        wgt = torch.sigmoid(torch.randn(B, 9, H, W, device=dem.device, generator=g))
+        off = 1.5 * torch.randn(B, 16, H, W, device=dem.device, generator=g)
+        sets.append((wgt.requires_grad_(), off.requires_grad_()))
+    w = model.postprocessor.w.detach().clone().requires_grad_()
+    b = model.postprocessor.b.detach().clone().requires_grad_()
+    gout = torch.randn(B, 1, H, W, device=dem.device, generator=g)
+    res = {}
+    outs = [ops.propagate(dem, wt, of, w, b) for wt, of in sets]
+    for name in ("fwd", "bwd"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for it in range(iters + 3):
+            wt, of = sets[it % nset]
+            if name == "fwd":
+                with torch.no_grad():
+                    e0.record()
+                    ops.propagate(dem, wt, of, w, b)
+                    e1.record()
+            else:
+                o = outs[it % nset]
+                e0.record()
+                torch.autograd.grad(o, (wt, of, w, b), gout, retain_graph=True)
+                e1.record()
+            e1.synchronize()
+            if it >= 3:
+                tot += e0.elapsed_time(e1)
+        res[name] = tot / iters * 1e-3
+    px = B * H * W
+    # 16-channel offset layout (centre pair dropped): 108 B/px forward, 208 B/px backward
+    fb, bb = 108.0 * px, 208.0 * px
+    bw_f, bw_b = fb / res["fwd"] / 1e9, bb / res["bwd"] / 1e9
+    return {
+        "bound": "hbm", "kernel": "prop_bwd_kernel<16>", "achieved": round(bw_b, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(bw_b / HBM_PEAK_GBS, 4), "traffic": None,
+        "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2),
+        "forward": {"kernel": "prop_fwd_kernel<16>", "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
+                    "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2)},
+        "note": "algorithmic bytes (SURVEY 8d, 16-ch offsets: 108/208 B per pixel) / event-timed launch "
+                "(includes host launch gap); rocprofv3 kernel-trace figure in profiles/",
+    }
+
+
+def cpu_baseline():
+    """Oracle (CPU restatement, fp32, torch CPU kernels) on one 512x512 tile: fwd + loss + bwd."""
+    from oracle import jspsr_ref as R
+    ic = {k: v for k, v in IN_CHANNELS.items() if k != "COP30"}
+    sd = R.make_state_dict(R.jspsr_param_shapes(ic, 32), seed=0)
+    for v in sd.values():
+        if v.is_floating_point() and v.dim() > 0:
+            v.requires_grad_()
+    for k in list(sd):
+        if "running" in k:
+            sd[k] = sd[k].detach()
+    cores = torch.get_num_threads()
+
+    def step(H):
+        inputs, gt = R.synthetic_batch(1, H, H, True, seed=0)
+        for v in sd.values():
+            if v.requires_grad:
+                v.grad = None
+        t0 = time.perf_counter()
+        pred = R.jspsr_forward(sd, inputs, True)
+        R.multi_loss(pred, gt)["Total"].backward()
+        return time.perf_counter() - t0
+
+    step(64)  # warm-up (allocator, thread pool)
+    t = step(TILE)
+    return {"value": round(TILE * TILE / t / 1e6, 5), "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/jspsr_ref.py (torch CPU fp32), 1 step fwd+loss+bwd on 1x{TILE}x{TILE} image+mask, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=TILES_PER_GPU, help="tiles per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+
+    from jspsr_amd import _lib
+    from jspsr_amd.JSPSR import Model
+    from jspsr_amd.ddp import GradReducer, broadcast_module
+    from jspsr_amd.losses import MultiLoss
+
+    _lib.load()  # fail loudly if the HIP library is missing
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = Model(in_channels=IN_CHANNELS, out_channels=1, num_feature=32, layers=(2, 2, 2, 2), spn=True).to(device).train()
+    broadcast_module(model)
+    reducer = GradReducer(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-6, fused=True)  # configs/*.yml:71-76
+    criterion = MultiLoss(1.0, 1.0, 0.1)
+    inputs, gt = synthetic_batch(args.batch, TILE, TILE, device, seed=1000 + rank)
+
+    def step():
+        reducer.zero_grad()
+        pred = model(*inputs)
+        loss = criterion(pred, gt)["Total"]
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = time_k1(model, inputs)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        px_per_step = args.batch * TILE * TILE * world
+        ms = dt / args.steps * 1e3
+        line = {
+            "metric": "Mpixels/sec fwd+bwd, JSPSR x8 on 512^2 DEM tiles",
+            "value": round(px_per_step / (dt / args.steps) / 1e6, 4),
+            "unit": "Mpixel/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "jspsr_r8_img_msk (image+mask guided, 43.87M params), "
+                            f"{args.batch} x {TILE}x{TILE} tiles per GPU, train step "
+                            "(fwd + L1/L2/Sobel loss + bwd + grad all-reduce + AdamW)",
+                "tiles_per_gpu": args.batch, "tile": TILE, "global_tiles": args.batch * world,
+                "parallelism": f"dp{world}", "final_loss": round(final_loss, 6),
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

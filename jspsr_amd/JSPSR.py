@@ -1,0 +1,149 @@
+"""``Model`` -- drop-in for the reference's ``models.JSPSR.Model`` (models/JSPSR.py:9-550).
+
+Same constructor, ``forward(*in_tensor)`` contract ([dem, img] or [dem, img, aux], contiguous
+fp32 NCHW on the device), attributes (``name``, ``in_channels``) and ``state_dict`` key set, so
+it can be handed to the reference's ``main.py`` train/eval loops and checkpoints unchanged
+(INTEGRATION.md).  All arithmetic runs in HIP kernels on gfx950 via jspsr_amd.engine.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .blocks import ConvUnit, ResUnit, UpUnit
+from .spn import Generator, PostProcessor
+
+_AUX_KEYS = ("mask", "canopy", "coord")
+
+
+class Model(nn.Module):
+    def __init__(self, in_channels: dict, out_channels: int = 1, num_feature: int = 32,
+                 layers: tuple = (2, 2, 2, 2), res_scale: tuple = (1, 1, 1, 1), spn: bool = True,
+                 spn_scale: int = 1):
+        super().__init__()
+        self.name = "JSPSR"
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.spn = spn
+        self.spn_scale = spn_scale
+        assert len(in_channels) > 1, "At least 2 input data are required"
+        if not spn:
+            raise NotImplementedError("spn=False (plain conv head) is outside the hot path")
+        nf = num_feature
+        self.flag_dem_img = "image" in in_channels
+        self.flag_dem_msk = "mask" in in_channels
+        self.flag_dem_canopy = "canopy" in in_channels
+        self.flag_dem_coord = "coord" in in_channels
+        # the reference wires exactly one auxiliary branch: mask, else canopy, else coord (:74-87)
+        self._aux = next((k for k in _AUX_KEYS if k in in_channels), None)
+        self._branches = ["dem"] + (["img"] if self.flag_dem_img else []) + (["aux"] if self._aux else [])
+        nb = len(self._branches)
+        if nb < 2:
+            raise AssertionError("At least one of image or mask is required")
+
+        self.conv_dem = ConvUnit(in_channels["lr_dem"], nf, 5, bn=False)
+        self.conv_img = ConvUnit(in_channels["image"], nf, 5, bn=True) if self.flag_dem_img else None
+        self.conv_aux = ConvUnit(in_channels[self._aux], nf, 5, bn=False) if self._aux else None
+
+        cin = nf
+        for s in range(4):
+            planes = nf * 2 * 2**s
+            stride = 1 if s == 0 else 2
+            for br in ("dem", "img", "aux"):
+                seq = None
+                if br in self._branches:
+                    first_in = cin * (nb if (br == "dem" and s > 0) else 1)
+                    units = [ResUnit(first_in, planes, stride, project=True, scale=res_scale[s])]
+                    units += [ResUnit(planes, planes, scale=res_scale[s]) for _ in range(1, layers[s])]
+                    seq = nn.Sequential(*units)
+                setattr(self, f"layer{s + 1}_{br}", seq)
+            setattr(self, f"guide{s + 1}", nn.Module())  # parameter-free concat (Guide, cat_only)
+            cin = planes
+        self.layer3d = UpUnit(nf * 16 * nb, nf * 8)
+        self.layer2d = UpUnit(nf * 8 + nf * 8 * nb, nf * 4)
+        self.layer1d = UpUnit(nf * 4 + nf * 4 * nb, nf * 2)
+        self.conv0 = ConvUnit(nf * 2 + nf * 2 * nb, nf * 2, 3, bn=True, relu=True, gate=True)
+        self.generator = Generator(in_channels=nf * 2, kernel_size=3, bc=nf)
+        self.postprocessor = PostProcessor(kernel_size=3, residual=True, scale=self.spn_scale)
+        self._initialize_weights()
+
+    # -- init: truncated normal +-2 sigma, sigma = sqrt(2.6 / (k*k*C_in)) (JSPSR.py:494-517) -------
+    def _initialize_weights(self):
+        try:
+            from scipy.stats import truncnorm  # same sampler / RNG stream as the reference
+        except ImportError:  # pragma: no cover
+            truncnorm = None
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.in_channels
+                std = math.sqrt(1.3 * 2.0 / n)
+                if truncnorm is not None:
+                    vals = truncnorm(-2.0, 2.0, loc=0.0, scale=std).rvs(m.weight.nelement())
+                    m.weight.data = torch.from_numpy(vals).type_as(m.weight.data).view_as(m.weight.data)
+                else:
+                    nn.init.trunc_normal_(m.weight, 0.0, std, -2 * std, 2 * std)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    @staticmethod
+    def parse_input(flag_dem_img, flag_dem_msk, flag_dem_canopy, flag_dem_coord, *in_tensor):
+        """Same contract and errors as models/JSPSR.py:519-550."""
+        assert flag_dem_msk or flag_dem_img or flag_dem_canopy, "At least one of image or mask is required"
+        dem = img = msk = canopy = coord = None
+        if len(in_tensor) == 3 and flag_dem_img:
+            if flag_dem_msk:
+                dem, img, msk = in_tensor
+            elif flag_dem_canopy:
+                dem, img, canopy = in_tensor
+            elif flag_dem_coord:
+                dem, img, coord = in_tensor
+            else:
+                raise NotImplementedError
+        elif len(in_tensor) == 2:
+            if flag_dem_img:
+                dem, img = in_tensor
+            elif flag_dem_msk:
+                dem, msk = in_tensor
+            elif flag_dem_canopy:
+                dem, canopy = in_tensor
+            elif flag_dem_coord:
+                dem, coord = in_tensor
+            else:
+                raise NotImplementedError
+        else:
+            raise NotImplementedError
+        return dem, img, msk, canopy, coord
+
+    def forward(self, *in_tensor):
+        dem, img, msk, canopy, coord = self.parse_input(
+            self.flag_dem_img, self.flag_dem_msk, self.flag_dem_canopy, self.flag_dem_coord, *in_tensor)
+        aux = msk if msk is not None else (canopy if canopy is not None else coord)
+        feats = {"dem": self.conv_dem(dem)}
+        if img is not None:
+            feats["img"] = self.conv_img(img)
+        if aux is not None:
+            feats["aux"] = self.conv_aux(aux)
+        order = [b for b in self._branches if b in feats]
+        if len(order) < 2:
+            raise NotImplementedError
+        fused = []
+        for s in range(1, 5):  # JSPSR.py:230-352
+            nxt = {}
+            for br in order:
+                src = fused[-1] if (br == "dem" and fused) else feats[br]
+                nxt[br] = getattr(self, f"layer{s}_{br}")(src)
+            feats = nxt
+            fused.append(E.cat([feats[b] for b in order]))
+        x = fused[3]
+        for up, skip in ((self.layer3d, fused[2]), (self.layer2d, fused[1]), (self.layer1d, fused[0])):
+            x = E.cat((up(x), skip))  # :354-368
+        c0 = self.conv0(x)
+        dem = dem.detach()  # :372
+        weight, off16 = self.generator.heads(self.generator.features(dem, c0))
+        return self.postprocessor(dem, weight, off16)  # 16-channel offsets: centre pair is implicit

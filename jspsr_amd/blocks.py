@@ -1,0 +1,92 @@
+"""Parameter containers whose state_dict keys equal the reference's, with
+forwards expressed through jspsr_amd.engine (HIP-backed operators).
+
+Key patterns reproduced: ``<unit>.conv.0.{weight,bias}``, ``<unit>.conv.bn.*``,
+``<unit>.camb.fc.{0,2}.weight`` (reference Basic2d, models/components/basics.py:23-60);
+``<up>.dconv.{0,1,bn}`` (Basic2dTrans, :63-85); ``<block>.{conv1,bn1,conv2,bn2,downsample.{0,1}}``
+(BasicBlock, :88-123).
+"""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from . import engine as E
+
+
+class ChannelGate(nn.Module):
+    """Holds the shared bias-free 1x1 MLP of ChannelAttention (resnet_cbam.py:36-53)."""
+
+    def __init__(self, channels: int, ratio: int = 16):
+        super().__init__()
+        self.fc = nn.Sequential()
+        self.fc.add_module("0", nn.Conv2d(channels, channels // ratio, 1, bias=False))
+        self.fc.add_module("2", nn.Conv2d(channels // ratio, channels, 1, bias=False))
+
+    def forward(self, x):
+        return E.channel_gate(x, self.fc[0].weight, self.fc[1].weight)
+
+
+class ConvUnit(nn.Module):
+    """[channel gate ->] conv kxk (bias iff no BN) [-> BN] [-> ReLU]."""
+
+    def __init__(self, cin, cout, kernel_size=3, bn=True, relu=True, gate=False):
+        super().__init__()
+        if gate:
+            self.camb = ChannelGate(cin)
+        self.conv = nn.Sequential()
+        self.conv.add_module("0", nn.Conv2d(cin, cout, kernel_size, 1, kernel_size // 2, bias=not bn))
+        if bn:
+            self.conv.add_module("bn", nn.BatchNorm2d(cout))
+        self.k = kernel_size
+        self.relu = relu
+
+    def forward(self, x):
+        if hasattr(self, "camb"):
+            x = self.camb(x)
+        c = self.conv[0]
+        y = E.conv2d(x, c.weight, c.bias, 1, self.k // 2)
+        if hasattr(self.conv, "bn"):
+            return E.batch_norm(y, self.conv.bn, relu=self.relu)
+        return E.bias_act(y, self.relu)
+
+
+class UpUnit(nn.Module):
+    """ConvUnit(gate, BN, ReLU) -> ConvTranspose2d k3 s2 p1 op1 -> BN -> ReLU."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.dconv = nn.Sequential()
+        self.dconv.add_module("0", ConvUnit(cin, cout, 3, bn=True, relu=True, gate=True))
+        self.dconv.add_module("1", nn.ConvTranspose2d(cout, cout, 3, 2, 1, 1, bias=False))
+        self.dconv.add_module("bn", nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = self.dconv[0](x)
+        y = E.conv_transpose2d(y, self.dconv[1].weight)
+        return E.batch_norm(y, self.dconv.bn, relu=True)
+
+
+class ResUnit(nn.Module):
+    """relu(bn2(conv3x3(relu(bn1(conv3x3_s(x))))) * scale + shortcut(x))."""
+
+    def __init__(self, cin, cout, stride=1, project=False, act=True, scale=1.0):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        self.stride, self.act, self.scale = stride, act, scale
+
+    def forward(self, x):
+        y = E.conv2d(x, self.conv1.weight, None, self.stride, 1)
+        y = E.batch_norm(y, self.bn1, relu=True)
+        y = E.conv2d(y, self.conv2.weight, None, 1, 1)
+        if self.downsample is not None:
+            r = E.conv2d(x, self.downsample[0].weight, None, self.stride, 0)
+            r = E.batch_norm(r, self.downsample[1])
+        else:
+            r = x
+        return E.batch_norm(y, self.bn2, relu=self.act, residual=r, res_scale=self.scale)

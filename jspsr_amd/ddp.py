@@ -1,0 +1,84 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI (backend "nccl" on ROCm).
+
+The reference is single-GPU; this is the new exchange step of BASELINE config 4.
+Design for xGMI (point-to-point links, ring collectives per-link bound): few, large buckets
+(default 64 MiB) carved from ONE flat fp32 buffer that the parameters' .grad tensors alias, so
+autograd accumulates straight into the communication buffer (no copy in, no copy out); buckets
+are filled in reverse parameter order -- the order backward produces gradients -- and each
+bucket's all-reduce is issued asynchronously from an autograd hook the moment its last
+gradient lands, overlapping the remaining backward.  BatchNorm statistics stay per replica
+(plain data-parallel semantics, matching the reference's numerics at the per-GPU batch).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, params, bucket_bytes: int = 64 << 20, process_group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        total = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        # reverse order = gradient production order; contiguous bucket ranges in the flat buffer
+        self.buckets = []  # (start, end, n_params)
+        self._bucket_of = {}
+        start = off = 0
+        count = 0
+        per = max(1, bucket_bytes // self.flat.element_size())
+        for p in reversed(self.params):
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[p] = len(self.buckets)
+            off += n
+            count += 1
+            if off - start >= per:
+                self.buckets.append((start, off, count))
+                start, count = off, 0
+        if count:
+            self.buckets.append((start, off, count))
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def zero_grad(self):
+        """Gradients alias the flat buffer: zero it in one kernel, keep the aliases."""
+        self.flat.zero_()
+        self._pending = [b[2] for b in self.buckets]
+        self._works = []
+
+    def _hook(self, p):
+        i = self._bucket_of[p]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            s, e, _ = self.buckets[i]
+            self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Wait for the in-flight bucket reductions and average."""
+        if self.world == 1:
+            return
+        for i, left in enumerate(self._pending):  # parameters that received no gradient this step
+            if left > 0:
+                s, e, _ = self.buckets[i]
+                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._pending[i] = 0
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self.flat.div_(self.world)
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
+    """Start every replica from rank `src`'s parameters and buffers."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src, group=group)

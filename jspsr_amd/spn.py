@@ -1,0 +1,70 @@
+"""Affinity/offset generator and propagation step -- the inner operator boundary of the hot
+path (reference: models/components/spn.py, ``Generator`` :8-75 and ``PostProcessor`` :79-118).
+Same class names, constructor arguments, parameter names and call signatures.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .blocks import ConvUnit, ResUnit
+
+
+class Generator(nn.Module):
+    """(dem, context) -> (weight (B,9,H,W) in (0,1), offset (B,18,H,W)); spn.py:54-75."""
+
+    def __init__(self, in_channels, kernel_size, block=None, bc=16, leaky=False):
+        super().__init__()
+        if kernel_size != 3 or leaky:
+            raise NotImplementedError("only the 3x3, ReLU generator the reference instantiates is built")
+        self.kernel_size = kernel_size
+        self.num = kernel_size * kernel_size - 1
+        self.idx_ref = self.num // 2
+        self.convd1 = ConvUnit(1, bc * 2, 3, bn=False)
+        self.convd2 = ConvUnit(bc * 2, bc * 2, 3, bn=False)
+        self.convf1 = ConvUnit(in_channels, bc * 2, 3, bn=False)
+        self.convf2 = ConvUnit(bc * 2, bc * 2, 3, bn=False)
+        self.conv = ConvUnit(bc * 4, bc * 4, 3, bn=False)
+        self.block = ResUnit(bc * 4, bc * 4)
+        self.conv_weight = nn.Sequential(nn.Conv2d(bc * 4, kernel_size**2, 1))
+        self.conv_offset = ConvUnit(bc * 4, 2 * self.num, 1, bn=False, relu=False)
+
+    def features(self, dem, context):
+        d = self.convd2(self.convd1(dem))
+        f = self.convf2(self.convf1(context))
+        return self.block(self.conv(E.cat((d, f))))
+
+    def heads(self, feature):
+        """weight (B,9,H,W) after the sigmoid and the 16 learned offset channels."""
+        cw, co = self.conv_weight[0], self.conv_offset.conv[0]
+        weight = E.sigmoid(E.conv2d(feature, cw.weight, cw.bias))
+        off16 = E.conv2d(feature, co.weight, co.bias)
+        return weight, off16
+
+    def forward(self, dem, context):
+        weight, off16 = self.heads(self.features(dem, context))
+        B, _, H, W = off16.shape
+        zero = torch.zeros(B, 2, H, W, dtype=off16.dtype, device=off16.device)
+        i = 2 * self.idx_ref
+        offset = torch.cat((off16[:, :i], zero, off16[:, i:]), 1)  # centre tap, spn.py:69-73
+        return weight.contiguous(), offset.contiguous()
+
+
+class PostProcessor(nn.Module):
+    """out = b + sum_k w_k (a_k - mean a) S_k + scale * dem; spn.py:99-118 (residual form only)."""
+
+    def __init__(self, kernel_size=3, residual=True, scale=1.0):
+        super().__init__()
+        if kernel_size != 3 or not residual:
+            raise NotImplementedError("only kernel_size=3, residual=True (what JSPSR/LRRU/EDSR use) is built")
+        self.residual = residual
+        self.w = nn.Parameter(torch.ones((1, 1, kernel_size, kernel_size)))
+        self.b = nn.Parameter(torch.zeros(1))
+        self.scale = scale
+        if self.scale != 1:
+            print("Warning: The scale factor is not 1. This may lead to unexpected results.")
+
+    def forward(self, init_dem, weight, offset):
+        """offset: (B,18,H,W) torchvision layout, or (B,16,H,W) without the zero centre pair."""
+        return E.propagate(init_dem, weight, offset, self.w, self.b, self.scale)

@@ -1,0 +1,64 @@
+"""CPU: host logic of the product package -- parameter tree, input contract, C-ABI exports."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import jspsr_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("ic", [{"lr_dem": 1, "image": 3}, {"lr_dem": 1, "image": 3, "mask": 15},
+                                {"lr_dem": 1, "mask": 15}])
+def test_state_dict_keys_match_reference_table(ic):
+    from jspsr_amd.JSPSR import Model
+    m = Model(dict(ic, COP30=1), num_feature=8)
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == list(R.jspsr_param_shapes(ic, 8).items())
+    assert m.name == "JSPSR" and m.in_channels.get("lr_dem") == 1
+    assert any("postprocessor" in k for k, _ in m.named_parameters())  # diff-LR group hook
+
+
+def test_reference_param_counts():
+    from jspsr_amd.JSPSR import Model
+    m = Model({"lr_dem": 1, "image": 3, "COP30": 1})
+    assert sum(p.numel() for p in m.parameters()) == 29_162_435 and len(m.state_dict()) == 326
+    assert torch.equal(m.postprocessor.w, torch.ones(1, 1, 3, 3)) and m.postprocessor.b.item() == 0
+
+
+def test_input_contract_errors():
+    from jspsr_amd.JSPSR import Model
+    m = Model({"lr_dem": 1, "image": 3}, num_feature=8)
+    x = torch.zeros(1, 1, 16, 16)
+    with pytest.raises(NotImplementedError):
+        m(x)
+    with pytest.raises(NotImplementedError):
+        m(x, x, x, x)
+    with pytest.raises(AssertionError):
+        Model({"lr_dem": 1})
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(x, torch.zeros(1, 3, 16, 16))  # CPU tensors: no fallback
+
+
+def test_cabi_exports_every_declared_symbol():
+    from jspsr_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "jspsr_hip.h")).read()
+    declared = set(re.findall(r"\b(jspsr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().jspsr_abi_version() == _lib.ABI_VERSION
+
+
+def test_cabi_argument_validation_without_gpu():
+    """Argument checks return error codes before any launch (safe on a box without a GPU)."""
+    from jspsr_amd import _lib
+    lib = _lib.load()
+    assert lib.jspsr_prop_forward_f32(None, None, None, 18, None, None, 1.0, None, 1, 8, 8, None) == -1
+    assert b"null" in lib.jspsr_last_error()
+    assert lib.jspsr_prop_backward_workspace_bytes(8, 512, 512) == 2048 * 10 * 4
+    assert lib.jspsr_prop_backward_workspace_bytes(0, 512, 512) == 0

@@ -1,0 +1,94 @@
+"""GPU parity: the product Model (HIP path) against the reference-made fixtures and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import jspsr_ref as R
+
+IMG = {"lr_dem": 1, "image": 3}
+MSK = {"lr_dem": 1, "image": 3, "mask": 15}
+CASES = [
+    ("g3_img_nf32_64_train.npz", IMG),
+    ("g3_img_nf32_64_eval.npz", IMG),
+    ("g3_img_nf8_b2_48x80_train.npz", IMG),
+    ("g4_msk_nf8_b2_64_train.npz", MSK),
+    ("g4_msk_nf8_b2_64_eval.npz", MSK),
+]
+
+
+def _build(z, ic):
+    from jspsr_amd.JSPSR import Model
+    nf, seed = int(z["nf"]), int(z["seed"])
+    B, H, W = (int(v) for v in z["BHW"])
+    sd = R.make_state_dict(R.jspsr_param_shapes(ic, nf), seed, torch.float64)
+    inputs, gt = R.synthetic_batch(B, H, W, "mask" in ic, seed=seed + 1, dtype=torch.float64)
+    s1 = sum(v.double().abs().sum().item() for v in sd.values())
+    if abs(s1 - float(z["param_abs_sum"])) > 1e-9 * s1:
+        pytest.skip("torch CPU generator stream differs from the fixture's")
+    m = Model(dict(ic, COP30=1), num_feature=nf)
+    m.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()})
+    return m.cuda(), [t.float().cuda() for t in inputs], gt.float().cuda()
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("name,ic", CASES)
+def test_model_matches_reference_fixture(golden_dir, name, ic):
+    """north_star tolerance: 1e-4 relative (fp32) against the reference's CPU result."""
+    z = np.load(os.path.join(golden_dir, name))
+    m, inputs, gt = _build(z, ic)
+    training = bool(z["training"])
+    m.train(training)
+    pred = m(*inputs)
+    assert pred.shape == gt.shape and pred.is_cuda
+    ref = torch.from_numpy(z["pred"])
+    assert (pred.detach().cpu().double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+    if not training:
+        return
+    loss = (pred - gt).abs().mean() + ((pred - gt) ** 2).mean()
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
+    loss.backward()
+    grads = dict(m.named_parameters())
+    worst = 0.0
+    for k, n in zip(z["grad_names"], z["grad_norms"]):
+        got = grads[str(k)].grad.double().norm().item()
+        worst = max(worst, abs(got - n) / max(n, 1e-12))
+    assert worst < 2e-3, worst  # norm of every one of the parameter gradients
+    for k in z.files:
+        if k.startswith("grad:"):
+            assert _rel(grads[k[5:]].grad, z[k]) < 5e-3, k
+        if k.startswith("buf:"):
+            assert _rel(m.state_dict()[k[4:]], z[k]) < 1e-4, k
+
+
+def test_generator_postprocessor_public_api():
+    """Generator.forward returns the 18-channel torchvision layout; PostProcessor accepts it."""
+    from jspsr_amd.spn import Generator, PostProcessor
+    torch.manual_seed(0)
+    gen, pp = Generator(16, 3, bc=8).cuda().eval(), PostProcessor().cuda()
+    dem = torch.rand(2, 1, 32, 48, device="cuda")
+    ctx = torch.randn(2, 16, 32, 48, device="cuda")
+    weight, offset = gen(dem, ctx)
+    assert weight.shape == (2, 9, 32, 48) and offset.shape == (2, 18, 32, 48)
+    assert offset[:, 8:10].abs().max().item() == 0 and weight.min().item() > 0 and weight.max().item() < 1
+    out = pp(dem, weight, offset)
+    ref = R.propagate(dem.cpu().double(), weight.detach().cpu().double(), offset.detach().cpu().double(),
+                      pp.w.detach().cpu().double(), pp.b.detach().cpu().double())
+    assert (out.detach().cpu().double() - ref).abs().max().item() < 5e-6
+
+
+def test_b2_dummy_batch_like_torchinfo():
+    """main.py:92 feeds B=2 dummy batches through the model at start-up (utils/utils.py:83-100)."""
+    from jspsr_amd.JSPSR import Model
+    m = Model({"COP30": 1, "image": 3, "mask": 15, "lr_dem": 1}, num_feature=8).cuda().eval()
+    with torch.no_grad():
+        y = m(torch.rand(2, 1, 128, 128, device="cuda"), torch.rand(2, 3, 128, 128, device="cuda"),
+              torch.rand(2, 15, 128, 128, device="cuda"))
+    assert y.shape == (2, 1, 128, 128) and torch.isfinite(y).all()
