@@ -67,6 +67,43 @@ int jspsr_prop_backward_f32(const float* grad_out, const float* dem, const float
                             float* grad_b0, void* workspace, int B, int H, int W,
                             jspsr_stream_t stream);
 
+/* ---- K2: convolutions on the matrix cores (implicit GEMM, NHWC) ---------------------------
+ * Replace the reference's nn.Conv2d / nn.ConvTranspose2d calls and their autograd
+ * (models/components/basics.py:6-20,39-47,69-77; every conv of models/JSPSR.py:66-180 and
+ * models/components/spn.py:16-52).  Activations are NHWC; a tensor argument is described by
+ * (pointer, C, channel pitch, channel offset) so a conv can read or write a channel slice of a
+ * wider buffer (the reference's torch.cat fusion, basics.py:134, needs no copy).
+ * dtype: JSPSR_F32 -> v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, fp32 storage);
+ *        JSPSR_BF16 -> v_mfma_f32_32x32x16_bf16 (bf16 storage, fp32 accumulate).
+ * Gathered channel counts / pitches / offsets must be multiples of 4 (fp32) or 8 (bf16).
+ */
+#define JSPSR_F32 0
+#define JSPSR_BF16 1
+
+/* Re-lay a master weight (O, I, KH, KW) fp32 (PyTorch Conv2d layout) for the kernels:
+ *   mode 0: packed[o][ky][kx][i]  (i zero-padded to c_pad) -- forward of Conv2d(I->O)
+ *   mode 1: packed[i][ky][kx][o]  (o zero-padded to c_pad) -- data gradient of Conv2d(I->O);
+ *           also the forward of ConvTranspose2d whose weight is stored (I_T=O, O_T=I, KH, KW).
+ */
+int jspsr_pack_weight(int dtype, const float* w, void* packed, int O, int I, int KH, int KW,
+                      int mode, int c_pad, jspsr_stream_t stream);
+
+/* out[b,oy,ox,n] = bias[n] + sum_{ky,kx,c} in[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * W[n,ky,kx,c]
+ * (+ ReLU if relu != 0).  wpack: mode-0 packing with c_pad = Cin.  bias may be NULL. */
+int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const float* bias, void* out,
+                         int B, int IH, int IW, int Cin, int in_cstride, int in_coff, int Cout,
+                         int out_cstride, int out_coff, int KH, int KW, int stride, int pad, int relu,
+                         jspsr_stream_t stream);
+
+/* gin[b,y,x,c] = bias[c] + sum_{ky,kx,n} gout[b,(y+pad-ky)/stride,(x+pad-kx)/stride,n] * W[n,c,ky,kx]
+ * over the taps where the division is exact: the data gradient of the conv above, and equally
+ * ConvTranspose2d(stride, pad) forward with gout := its input (IH, IW = its output size).
+ * wpack_t: mode-1 packing with c_pad = Cg.  One launch per stride phase (no wasted taps). */
+int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,
+                       int B, int OH, int OW, int Cg, int g_cstride, int g_coff, int IH, int IW,
+                       int Cin, int in_cstride, int in_coff, int KH, int KW, int stride, int pad,
+                       int relu, jspsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,9 @@ SIGNATURES = {
     "jspsr_prop_forward_f32": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "jspsr_prop_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_prop_backward_f32": (c_i, [c_p] * 4 + [c_i] + [c_p] * 6 + [c_i, c_i, c_i, c_p]),
+    "jspsr_pack_weight": (c_i, [c_i, c_p, c_p] + [c_i] * 6 + [c_p]),
+    "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p]),
+    "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p]),
 }
 
 

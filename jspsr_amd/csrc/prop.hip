@@ -23,15 +23,13 @@
 namespace {
 
 constexpr int TW = 64;    // tile width  (pixels)
-constexpr int TH = 16;    // tile height (rows)
 constexpr int HALO = 8;   // LDS halo on every side
 constexpr int LW = TW + 2 * HALO;  // 80
-constexpr int LH = TH + 2 * HALO;  // 32
 constexpr int NT = 256;   // threads per workgroup
 constexpr int NRED = 10;  // grad_wk[9] + grad_b0
 
 struct Geom {
-  int B, H, W, tiles_x, tiles_y, nblk;
+  int B, H, W, tiles_x, tiles_y, nblk, th;
 };
 
 // PX consecutive pixels of one plane per lane: PX*4-byte loads when the row pitch and the
@@ -75,7 +73,7 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const Vec<PX>& r, int
 }
 
 // Stage the DEM tile + halo of image `img` into LDS; zero outside the raster.
-template <bool VEC>
+template <bool VEC, int LH>
 __device__ __forceinline__ void stage_dem(float* __restrict__ lds, const float* __restrict__ img,
                                           int ty0, int tx0, int H, int W) {
   for (int i = threadIdx.x; i < LH * (LW / 4); i += NT) {
@@ -103,6 +101,7 @@ struct Corners {
 
 // The four bilinear corners of position (py,px); out-of-raster corners are 0
 // (torchvision bilinear_interpolate / get_coordinate_weight corner rule).
+template <int LH>
 __device__ __forceinline__ Corners corners(const float* __restrict__ lds,
                                            const float* __restrict__ img, int H, int W,
                                            int ly0, int lx0, float py, float px) {
@@ -142,7 +141,7 @@ __device__ __forceinline__ void tile_coords(const Geom& g, int& b, int& ty0, int
   const int per_img = g.tiles_x * g.tiles_y;
   b = t / per_img;
   const int r = t - b * per_img;
-  ty0 = (r / g.tiles_x) * TH;
+  ty0 = (r / g.tiles_x) * g.th;
   tx0 = (r % g.tiles_x) * TW;
 }
 
@@ -155,13 +154,14 @@ __device__ __forceinline__ constexpr int och(int k, int c) {
 // Lane -> pixel map: a row of the tile is TW/PX lanes wide; a workgroup pass covers
 // RPP = NT*PX/TW rows and the tile's TH rows take TH/RPP passes (not unrolled: it bounds the
 // live registers to one pass; occupancy, not unrolling, hides the HBM latency).
-template <int OC, int PX, bool VEC>
+template <int OC, int PX, bool VEC, int TH>
 __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ dem,
                                                      const float* __restrict__ weight,
                                                      const float* __restrict__ offset,
                                                      const float* __restrict__ wk,
                                                      const float* __restrict__ b0, float scale,
                                                      float* __restrict__ out, Geom g) {
+  constexpr int LH = TH + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float lds[LH * LW];
   constexpr int LPR = TW / PX;       // lanes per tile row
   constexpr int RPP = NT / LPR;      // rows per pass
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
   const int H = g.H, W = g.W;
   const size_t P = (size_t)H * W;
   const float* img = dem + (size_t)b * P;
-  stage_dem<VEC>(lds, img, ty0, tx0, H, W);
+  stage_dem<VEC, LH>(lds, img, ty0, tx0, H, W);
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
       for (int k = 0; k < 9; ++k) {
         const float py = (float)(y - 1 + k / 3) + oy[k].v[j];
         const float px = (float)(x + j - 1 + k % 3) + ox[k].v[j];
-        const Corners c = corners(lds, img, H, W, ly0, lx0, py, px);
+        const Corners c = corners<LH>(lds, img, H, W, ly0, lx0, py, px);
         const float hy = 1.f - c.ly, hx = 1.f - c.lx;
         const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
         acc += wreg[k] * (a[k].v[j] - mean) * S;
@@ -221,12 +221,13 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
   }
 }
 
-template <int OC, int PX, bool VEC>
+template <int OC, int PX, bool VEC, int TH>
 __global__ __launch_bounds__(NT) void prop_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ dem,
     const float* __restrict__ weight, const float* __restrict__ offset,
     const float* __restrict__ wk, float* __restrict__ gweight, float* __restrict__ goffset,
     float* __restrict__ partial, Geom g) {
+  constexpr int LH = TH + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float lds[LH * LW];
   __shared__ float red[NT / 64][NRED];
   constexpr int LPR = TW / PX;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
   const int H = g.H, W = g.W;
   const size_t P = (size_t)H * W;
   const float* img = dem + (size_t)b * P;
-  stage_dem<VEC>(lds, img, ty0, tx0, H, W);
+  stage_dem<VEC, LH>(lds, img, ty0, tx0, H, W);
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
         for (int k = 0; k < 9; ++k) {
           const float py = (float)(y - 1 + k / 3) + oy[k].v[j];
           const float px = (float)(x + j - 1 + k % 3) + ox[k].v[j];
-          const Corners c = corners(lds, img, H, W, ly0, lx0, py, px);
+          const Corners c = corners<LH>(lds, img, H, W, ly0, lx0, py, px);
           const float hy = 1.f - c.ly, hx = 1.f - c.lx;
           const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
           const float dSdy = hx * (c.v10 - c.v00) + c.lx * (c.v11 - c.v01);
@@ -345,13 +346,24 @@ __global__ __launch_bounds__(64 * NRED) void prop_bwd_finalize(const float* __re
   }
 }
 
+// Tile height.  Tunable through JSPSR_PROP_TH (4, 8 or 16).
+int prop_th() {
+  static const int th = [] {
+    const char* e = getenv("JSPSR_PROP_TH");
+    const int v = e ? atoi(e) : 16;
+    return (v == 4 || v == 8 || v == 16) ? v : 16;
+  }();
+  return th;
+}
+
 int make_geom(int B, int H, int W, Geom& g) {
   if (B <= 0 || H <= 0 || W <= 0) return jspsr::fail(JSPSR_EINVAL, "prop: bad shape B=%d H=%d W=%d", B, H, W);
   g.B = B;
   g.H = H;
   g.W = W;
   g.tiles_x = (W + TW - 1) / TW;
-  g.tiles_y = (H + TH - 1) / TH;
+  g.th = prop_th();
+  g.tiles_y = (H + g.th - 1) / g.th;
   const long long n = (long long)B * g.tiles_x * g.tiles_y;
   if (n > 0x7fffffffLL || (long long)B * 18 * H * W > (1LL << 40))
     return jspsr::fail(JSPSR_EINVAL, "prop: problem too large");
@@ -394,11 +406,13 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
   const bool vec = can_vec(W, px, {dem, weight, offset, out});
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(g.nblk), block(NT);
-#define LAUNCH(OC, PX, V) hipLaunchKernelGGL((prop_fwd_kernel<OC, PX, V>), grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g)
+#define LAUNCH_TH(OC, PX, V, T) hipLaunchKernelGGL((prop_fwd_kernel<OC, PX, V, T>), grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g)
+#define LAUNCH(OC, PX, V) do { if (g.th == 16) LAUNCH_TH(OC, PX, V, 16); else if (g.th == 8) LAUNCH_TH(OC, PX, V, 8); else LAUNCH_TH(OC, PX, V, 4); } while (0)
 #define BY_VEC(OC, PX) do { if (vec) LAUNCH(OC, PX, true); else LAUNCH(OC, PX, false); } while (0)
 #define BY_PX(OC) do { if (px == 1) LAUNCH(OC, 1, true); else if (px == 2) BY_VEC(OC, 2); else BY_VEC(OC, 4); } while (0)
   if (offset_channels == 18) BY_PX(18); else BY_PX(16);
 #undef LAUNCH
+#undef LAUNCH_TH
   return jspsr::check_launch("prop_forward");
 }
 
@@ -428,9 +442,11 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   dim3 grid(g.nblk), block(NT);
-#define LAUNCH(OC, PX, V) hipLaunchKernelGGL((prop_bwd_kernel<OC, PX, V>), grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g)
+#define LAUNCH_TH(OC, PX, V, T) hipLaunchKernelGGL((prop_bwd_kernel<OC, PX, V, T>), grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g)
+#define LAUNCH(OC, PX, V) do { if (g.th == 16) LAUNCH_TH(OC, PX, V, 16); else if (g.th == 8) LAUNCH_TH(OC, PX, V, 8); else LAUNCH_TH(OC, PX, V, 4); } while (0)
   if (offset_channels == 18) BY_PX(18); else BY_PX(16);
 #undef LAUNCH
+#undef LAUNCH_TH
 #undef BY_VEC
 #undef BY_PX
   if (int e = jspsr::check_launch("prop_backward")) return e;

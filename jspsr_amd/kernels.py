@@ -1,0 +1,84 @@
+"""Thin, autograd-free Python wrappers over the C ABI (include/jspsr_hip.h).
+
+Activations are NHWC torch tensors of shape (B, H, W, C), contiguous, fp32 or bf16, on the GPU;
+torch only owns the memory.  Every function launches on the current HIP stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def epc(dtype: torch.dtype) -> int:
+    """Channel granularity of gathered tensors: elements per 16-byte chunk."""
+    return 4 if dtype == torch.float32 else 8
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: jspsr_amd kernels run on the GPU only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+def pack_weight(w: torch.Tensor, mode: int, c_pad: int, dtype: torch.dtype) -> torch.Tensor:
+    """(O,I,KH,KW) fp32 master -> [O][KH][KW][c_pad] (mode 0) or [I][KH][KW][c_pad] (mode 1)."""
+    _chk(w, "pack_weight")
+    O, I, KH, KW = w.shape
+    n = O if mode == 0 else I
+    out = torch.empty((n, KH, KW, c_pad), dtype=dtype, device=w.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_pack_weight(_dt(out), w.data_ptr(), out.data_ptr(), O, I, KH, KW, mode, c_pad, _stream()),
+               "jspsr_pack_weight")
+    return out
+
+
+def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0, cin=None, in_coff=0):
+    """x (B,IH,IW,Cs) NHWC, wpack [Cout][KH][KW][Cin] -> (B,OH,OW,Cout) (or a slice of `out`)."""
+    _chk(x, "conv2d_forward")
+    B, IH, IW, Cs = x.shape
+    Cout, KH, KW, Cin = wpack.shape
+    if cin is not None and cin != Cin:
+        raise ValueError("conv2d_forward: cin mismatch")
+    OH = (IH + 2 * pad - KH) // stride + 1
+    OW = (IW + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((B, OH, OW, Cout), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_conv2d_forward(_dt(x), x.data_ptr(), wpack.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                        B, IH, IW, Cin, Cs, in_coff, Cout, out.shape[3], out_coff,
+                                        KH, KW, stride, pad, int(relu), _stream()), "jspsr_conv2d_forward")
+    return out
+
+
+def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0):
+    """g (B,OH,OW,Cgs) NHWC, wpack_t [Cin][KH][KW][Cg] -> (B,IH,IW,Cin): data gradient of a conv /
+    forward of a transposed conv."""
+    _chk(g, "conv2d_dgrad")
+    B, OH, OW, Cgs = g.shape
+    Cin, KH, KW, Cg = wpack_t.shape
+    IH, IW = in_hw
+    if out is None:
+        out = torch.empty((B, IH, IW, Cin), dtype=g.dtype, device=g.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_conv2d_dgrad(_dt(g), g.data_ptr(), wpack_t.data_ptr(),
+                                      bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                      B, OH, OW, Cg, Cgs, g_coff, IH, IW, Cin, out.shape[3], out_coff,
+                                      KH, KW, stride, pad, int(relu), _stream()), "jspsr_conv2d_dgrad")
+    return out

@@ -1,0 +1,118 @@
+"""GPU parity: K2 implicit-GEMM convolutions (HIP/MFMA, through the C ABI) against torch CPU fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _k():
+    from jspsr_amd import kernels
+    return kernels
+
+
+def _nhwc(t):  # (B,C,H,W) cpu -> (B,H,W,C) cuda contiguous
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def _relerr(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 24, 32, 64, 3, 1, 1),
+    (1, 40, 36, 64, 128, 3, 1, 1),
+    (2, 33, 47, 32, 32, 3, 1, 1),       # ragged M
+    (1, 32, 32, 192, 128, 3, 2, 1),     # stride-2 first block
+    (2, 16, 16, 64, 128, 1, 2, 0),      # 1x1 stride-2 shortcut
+    (1, 24, 24, 128, 9, 1, 1, 0),       # head, tiny N
+    (1, 24, 24, 128, 16, 1, 1, 0),
+    (2, 20, 20, 4, 32, 5, 1, 2),        # stem, padded 1/3 -> 4 channels
+    (1, 20, 28, 16, 32, 5, 1, 2),       # stem, 15 -> 16
+    (1, 8, 8, 1536, 256, 3, 1, 1),      # deep K
+    (1, 17, 19, 8, 200, 3, 1, 1),       # N not a tile multiple
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", CASES)
+def test_conv_forward(dtype, B, H, W, Cin, Cout, k, stride, pad):
+    K = _k()
+    if Cin % K.epc(dtype):
+        pytest.skip("channel granularity")
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()  # same rounded operands on both sides
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), stride, pad))
+    wp = K.pack_weight(w.cuda(), 0, Cin, dtype)
+    y = K.conv2d_forward(_nhwc(x).to(dtype), wp, bias.cuda(), stride, pad, relu=True)
+    tol = 2e-6 if dtype == torch.float32 else 6e-3
+    assert _relerr(_nchw(y.float()), ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", CASES)
+def test_conv_dgrad(dtype, B, H, W, Cin, Cout, k, stride, pad):
+    """dX of the conv == conv_transpose2d(gout, W)."""
+    K = _k()
+    e = K.epc(dtype)
+    Cg = (Cout + e - 1) // e * e  # gathered tensor (gout) is channel-padded to the chunk size
+    g = torch.Generator().manual_seed(B * 77 + H + Cin + Cout)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    go = torch.randn(B, Cout, OH, OW, generator=g)
+    if dtype == torch.bfloat16:
+        go, w = go.bfloat16().float(), w.bfloat16().float()
+    x = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w.double(), None, stride, pad).backward(go.double())
+    wpt = K.pack_weight(w.cuda(), 1, Cg, dtype)
+    gop = F.pad(go, (0, 0, 0, 0, 0, Cg - Cout))
+    dx = K.conv2d_dgrad(_nhwc(gop).to(dtype), wpt, (H, W), stride, pad)
+    tol = 2e-6 if dtype == torch.float32 else 6e-3
+    assert _relerr(_nchw(dx.float()), x.grad) < tol
+
+
+@pytest.mark.parametrize("C", [64, 256])
+def test_conv_transpose_forward(C):
+    """ConvTranspose2d k3 s2 p1 op1 (basics.py:69-77) == dgrad launch with the (I,O,KH,KW) weight."""
+    K = _k()
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(2, C, 12, 10, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5  # ConvTranspose2d weight: (in, out, kh, kw)
+    ref = F.conv_transpose2d(x.double(), w.double(), None, 2, 1, 1)
+    wpt = K.pack_weight(w.cuda(), 1, C, torch.float32)  # [out_T][ky][kx][in_T]
+    y = K.conv2d_dgrad(_nhwc(x), wpt, (24, 20), 2, 1)
+    assert _relerr(_nchw(y), ref) < 2e-6
+
+
+def test_channel_slices():
+    """A conv can read a channel slice and write into a slice of a wider (concat) buffer."""
+    K = _k()
+    g = torch.Generator().manual_seed(9)
+    xw = torch.randn(1, 96, 16, 16, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17
+    ref = F.conv2d(xw[:, 32:64].double(), w.double(), None, 1, 1)
+    wp = K.pack_weight(w.cuda(), 0, 32, torch.float32)
+    out = torch.full((1, 16, 16, 160), 7.0, device="cuda")
+    K.conv2d_forward(_nhwc(xw), wp, None, 1, 1, out=out, out_coff=64, in_coff=32)
+    assert _relerr(_nchw(out[..., 64:128].contiguous()), ref) < 2e-6
+    assert (out[..., :64] == 7).all() and (out[..., 128:] == 7).all()
+
+
+def test_bad_arguments_raise():
+    K = _k()
+    from jspsr_amd._lib import JspsrHipError
+    x = torch.zeros(1, 8, 8, 6, device="cuda")  # 6 channels: not a multiple of 4
+    wp = torch.zeros(8, 3, 3, 6, device="cuda")
+    with pytest.raises(JspsrHipError):
+        K.conv2d_forward(x, wp, None, 1, 1)
+    with pytest.raises(RuntimeError):
+        K.conv2d_forward(torch.zeros(1, 8, 8, 8), wp, None, 1, 1)
