@@ -104,6 +104,21 @@ int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const f
                        int Cin, int in_cstride, int in_coff, int KH, int KW, int stride, int pad,
                        int relu, jspsr_stream_t stream);
 
+/* Weight gradient (autograd of nn.Conv2d / nn.ConvTranspose2d w.r.t. .weight):
+ *   dW[r][c][ky][kx] = sum_{b,oy,ox} G[b,oy,ox,r] * X[b, oy*stride-pad+ky, ox*stride-pad+kx, c]
+ * G lives on the conv's output grid (B,OH,OW,Cg), X on its input grid (B,IH,IW,Cx); Cg, Cx are the
+ * chunk-padded channel counts, R <= Cg and C <= Cx the real ones; dW is fp32 in PyTorch's
+ * (R, C, KH, KW) layout and is overwritten (accumulate == 0) or added to (accumulate != 0).
+ * Conv2d(I->O): G = grad_out, X = input, R = O, C = I.  ConvTranspose2d(I->O, weight (I,O,KH,KW)):
+ * G = its input, X = grad of its output, R = I, C = O.
+ * workspace: jspsr_conv2d_wgrad_workspace_bytes() bytes (split-K slabs, summed in a fixed order).
+ */
+size_t jspsr_conv2d_wgrad_workspace_bytes(int dtype, int B, int OH, int OW, int Cg, int Cx, int KH, int KW);
+int jspsr_conv2d_wgrad(int dtype, const void* G, int Cg, int g_cstride, int g_coff, const void* X, int Cx,
+                       int x_cstride, int x_coff, float* dW, int R, int C, int B, int OH, int OW,
+                       int IH, int IW, int KH, int KW, int stride, int pad, int accumulate,
+                       void* workspace, jspsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,8 @@ SIGNATURES = {
     "jspsr_pack_weight": (c_i, [c_i, c_p, c_p] + [c_i] * 6 + [c_p]),
     "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p]),
     "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p]),
+    "jspsr_conv2d_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i] * 8),
+    "jspsr_conv2d_wgrad": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p, c_p]),
 }
 
 

@@ -1,0 +1,317 @@
+// K2w -- weight gradient of a convolution on MFMA (the autograd of nn.Conv2d / nn.ConvTranspose2d
+// w.r.t. the weight; reference call site: loss.backward(), train/train_utils.py:217).
+//
+//   dW[r][ky][kx][c] = sum over m-pixels (b,oy,ox) of  G[b,oy,ox,r] * X[b, oy*s-p+ky, ox*s-p+kx, c]
+//
+// GEMM view: rows = channels of G (the tensor living on the conv's OUTPUT grid), columns = flattened
+// (tap, channel of X), reduction = pixels.  Both operand tiles are staged in LDS exactly as they
+// lie in memory ([pixel][channel], channel contiguous):
+//   fp32: an MFMA 32x32x2 operand is one value per lane, lanes = consecutive channels of one pixel
+//         row -> conflict-free ds_read_b32;
+//   bf16: an MFMA 32x32x16 operand is 8 consecutive PIXELS per lane -> ds_read_b64_tr_b16
+//         (hardware transposing LDS read), two per operand; row pitch padded so the 4 rows of a
+//         block fall in different banks.
+// Split over pixel ranges (grid.z) so every layer fills the chip; slabs are summed in a fixed
+// order by a second kernel that also writes the master (R, C, KH, KW) fp32 layout -> bit-reproducible.
+#include "conv_igemm.h"
+
+namespace {
+
+using namespace jspsr;
+
+constexpr int NT = 256;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+struct WgradGeom {
+  int B, OH, OW;            // m-space (grid of G)
+  int Cg, g_cs, g_coff;     // G channels / pitch / offset
+  int IH, IW;               // grid of X
+  int Cx, x_cs, x_coff;     // X channels (chunk-padded) / pitch / offset
+  int KH, KW, stride, pad;
+  int Ktot;                 // KH*KW*Cx
+  int m_per_split;          // pixels per grid.z slice (multiple of the stage depth)
+  long long M;
+};
+
+template <typename T> struct WT;
+template <> struct WT<float> { static constexpr int EPC = 4, BKM = 32; };
+template <> struct WT<__bf16> { static constexpr int EPC = 8, BKM = 64; };
+
+__host__ __device__ constexpr int pitch_bytes(int row_bytes) {
+  return row_bytes + ((row_bytes % 128 == 0) ? 64 : 0);
+}
+
+template <typename T, int BMC, int BNC, int WGM, int WGN>
+__global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, const T* __restrict__ X,
+                                                     float* __restrict__ ws, WgradGeom g) {
+  constexpr int EPC = WT<T>::EPC, BKM = WT<T>::BKM;
+  constexpr int WTM = BMC / WGM, WTN = BNC / WGN, MI = WTM / 32, NI = WTN / 32;
+  constexpr int GP = pitch_bytes(BMC * sizeof(T)), XP = pitch_bytes(BNC * sizeof(T));
+  constexpr int CPR_G = BMC / EPC, CPR_X = BNC / EPC;  // 16-byte chunks per tile row
+  constexpr int G_IT = (BKM * CPR_G + NT - 1) / NT, X_IT = BKM * CPR_X / NT;
+  constexpr int G_RSTEP = NT / CPR_G, X_RSTEP = NT / CPR_X;
+  static_assert(WGM * WGN == 4 && MI >= 1 && NI >= 1 && NT % CPR_G == 0 && NT % CPR_X == 0, "tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Gs = smem;                    // [2][BKM][GP]
+  char* Xs = smem + 2 * BKM * GP;     // [2][BKM][XP]
+
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.x * BMC, n0 = blockIdx.y * BNC;
+  const long long m_begin = (long long)blockIdx.z * g.m_per_split;
+  const long long m_end = (m_begin + g.m_per_split < g.M) ? m_begin + g.m_per_split : g.M;
+  const int KT = (int)((m_end - m_begin + BKM - 1) / BKM);
+
+  // G staging: chunk gc of rows gr0 + i*G_RSTEP
+  const int gc = tid % CPR_G, gr0 = tid / CPR_G;
+  const bool g_colok = co0 + gc * EPC < g.Cg;
+  // X staging: chunk xc (a fixed (tap, channel) column group) of rows xr0 + i*X_RSTEP
+  const int xc = tid % CPR_X, xr0 = tid / CPR_X;
+  const int kcol = n0 + xc * EPC;
+  const bool x_colok = kcol < g.Ktot;
+  const int tap = x_colok ? kcol / g.Cx : 0, cix = x_colok ? kcol % g.Cx : 0;
+  const int ky = tap / g.KW, kx = tap % g.KW;
+  // pixel coordinates of this thread's X rows, advanced incrementally per stage
+  int xb[X_IT], xoy[X_IT], xox[X_IT];
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const long long m = m_begin + xr0 + i * X_RSTEP;
+    xox[i] = (int)(m % g.OW);
+    const long long tq = m / g.OW;
+    xoy[i] = (int)(tq % g.OH);
+    xb[i] = (int)(tq / g.OH);
+  }
+
+  uint4 greg[G_IT], xreg[X_IT];
+  auto load_stage = [&](int kt) {
+    const long long mb = m_begin + (long long)kt * BKM;
+#pragma unroll
+    for (int i = 0; i < G_IT; ++i) {
+      const int r = gr0 + i * G_RSTEP;
+      const long long m = mb + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g_colok && r < BKM && m < m_end)
+        v = *reinterpret_cast<const uint4*>(G + (size_t)m * g.g_cs + g.g_coff + co0 + gc * EPC);
+      greg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const long long m = mb + xr0 + i * X_RSTEP;
+      const int iy = xoy[i] * g.stride - g.pad + ky, ix = xox[i] * g.stride - g.pad + kx;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (x_colok && m < m_end && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) {
+        const size_t pix = ((size_t)xb[i] * g.IH + iy) * g.IW + ix;
+        v = *reinterpret_cast<const uint4*>(X + pix * g.x_cs + g.x_coff + cix);
+      }
+      xreg[i] = v;
+      // advance this row by one stage (BKM pixels) for the next call
+      xox[i] += BKM;
+      while (xox[i] >= g.OW) {
+        xox[i] -= g.OW;
+        if (++xoy[i] == g.OH) { xoy[i] = 0; ++xb[i]; }
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < G_IT; ++i) {
+      const int r = gr0 + i * G_RSTEP;
+      if (r < BKM) *reinterpret_cast<uint4*>(Gs + (buf * BKM + r) * GP + gc * 16) = greg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i)
+      *reinterpret_cast<uint4*>(Xs + (buf * BKM + xr0 + i * X_RSTEP) * XP + xc * 16) = xreg[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  if (KT > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) load_stage(kt + 1);
+    const char* Gb = Gs + buf * BKM * GP;
+    const char* Xb = Xs + buf * BKM * XP;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll 4
+      for (int s = 0; s < BKM / 2; ++s) {
+        float a[MI], b[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          a[mi] = *reinterpret_cast<const float*>(Gb + (2 * s + lh) * GP + (wm * WTM + mi * 32 + lr) * 4);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          b[ni] = *reinterpret_cast<const float*>(Xb + (2 * s + lh) * XP + (wn * WTN + ni * 32 + lr) * 4);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+    } else {
+      // transposing reads: lane (4q+p) of a 16-lane group addresses row q, columns 4p..4p+3 of a
+      // 4-pixel x 16-channel block and receives column (lane&15) of the 4 rows.
+      const int grp16 = (lane >> 4) & 1, li = lane & 15, q = li >> 2, pp = li & 3;
+#pragma unroll
+      for (int kb = 0; kb < BKM / 16; ++kb) {
+        bf16x8 a[MI], b[NI];
+        const int row0 = kb * 16 + 8 * lh + q;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const char* p = Gb + row0 * GP + (wm * WTM + mi * 32 + 16 * grp16 + 4 * pp) * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * GP));
+          a[mi] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const char* p = Xb + row0 * XP + (wn * WTN + ni * 32 + 16 * grp16 + 4 * pp) * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * XP));
+          b[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* slab = ws + (size_t)blockIdx.z * g.Cg * g.Ktot;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int k = n0 + wn * WTN + ni * 32 + lr;
+    if (k >= g.Ktot) continue;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (co < g.Cg) slab[(size_t)co * g.Ktot + k] = acc[mi][ni][e];
+      }
+  }
+}
+
+// dW[r][c][ky][kx] (+)= sum_z ws[z][r][(ky*KW+kx)*Cx + c],  r < R, c < C  (fixed summation order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int R, int C, int KH,
+                                    int KW, int Cg, int Cx, int splits, int accumulate) {
+  const long long total = (long long)R * C * KH * KW;
+  const size_t slab = (size_t)Cg * KH * KW * Cx;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    long long t = idx;
+    const int kx = (int)(t % KW); t /= KW;
+    const int ky = (int)(t % KH); t /= KH;
+    const int c = (int)(t % C);
+    const int r = (int)(t / C);
+    const size_t src = (size_t)r * KH * KW * Cx + (size_t)(ky * KW + kx) * Cx + c;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[z * slab + src];
+    dW[idx] = accumulate ? dW[idx] + s : s;
+  }
+}
+
+struct Plan {
+  int bmc, splits, m_per_split;
+};
+
+template <typename T>
+Plan make_plan(long long M, int Cg, int Ktot) {
+  Plan p;
+  p.bmc = Cg > 64 ? 128 : (Cg > 32 ? 64 : 32);
+  const int BKM = WT<T>::BKM;
+  const long long tiles = (long long)((Cg + p.bmc - 1) / p.bmc) * ((Ktot + 127) / 128);
+  long long splits = (1024 + tiles - 1) / tiles;        // aim at ~4 workgroups per CU
+  const long long max_splits = (M + 4 * BKM - 1) / (4 * BKM);  // >= 4 stages per slice
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  long long per = (M + splits - 1) / splits;
+  per = (per + BKM - 1) / BKM * BKM;
+  p.m_per_split = (int)per;
+  p.splits = (int)((M + per - 1) / per);
+  return p;
+}
+
+template <typename T, int BMC, int WGM, int WGN>
+int launch_w(const void* G, const void* X, float* ws, const WgradGeom& g, int splits, hipStream_t s) {
+  constexpr int BNC = 128, BKM = WT<T>::BKM;
+  constexpr size_t lds = 2 * BKM * (pitch_bytes(BMC * sizeof(T)) + pitch_bytes(BNC * sizeof(T)));
+  auto kern = wgrad_kernel<T, BMC, BNC, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid((g.Cg + BMC - 1) / BMC, (g.Ktot + BNC - 1) / BNC, splits);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, static_cast<const T*>(G), static_cast<const T*>(X), ws, g);
+  return check_launch("conv2d_wgrad");
+}
+
+template <typename T>
+int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradGeom& g, int accumulate, hipStream_t s) {
+  const Plan p = make_plan<T>(g.M, g.Cg, g.Ktot);
+  g.m_per_split = p.m_per_split;
+  int e;
+  if (p.bmc == 128) e = launch_w<T, 128, 2, 2>(G, X, ws, g, p.splits, s);
+  else if (p.bmc == 64) e = launch_w<T, 64, 2, 2>(G, X, ws, g, p.splits, s);
+  else e = launch_w<T, 32, 1, 4>(G, X, ws, g, p.splits, s);
+  if (e) return e;
+  const long long total = (long long)R * C * g.KH * g.KW;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dW, R, C, g.KH, g.KW, g.Cg, g.Cx,
+                     p.splits, accumulate);
+  return check_launch("conv2d_wgrad_reduce");
+}
+
+}  // namespace
+
+extern "C" size_t jspsr_conv2d_wgrad_workspace_bytes(int dtype, int B, int OH, int OW, int Cg, int Cx, int KH, int KW) {
+  if (B <= 0 || OH <= 0 || OW <= 0 || Cg <= 0 || Cx <= 0 || KH <= 0 || KW <= 0) return 0;
+  const long long M = (long long)B * OH * OW;
+  const int Ktot = KH * KW * Cx;
+  const Plan p = dtype == JSPSR_BF16 ? make_plan<__bf16>(M, Cg, Ktot) : make_plan<float>(M, Cg, Ktot);
+  return (size_t)p.splits * Cg * Ktot * sizeof(float);
+}
+
+extern "C" int jspsr_conv2d_wgrad(int dtype, const void* G, int Cg, int g_cstride, int g_coff, const void* X, int Cx,
+                                  int x_cstride, int x_coff, float* dW, int R, int C, int B, int OH, int OW,
+                                  int IH, int IW, int KH, int KW, int stride, int pad, int accumulate,
+                                  void* workspace, jspsr_stream_t stream) {
+  if (dtype != JSPSR_F32 && dtype != JSPSR_BF16) return fail(JSPSR_EINVAL, "conv2d_wgrad: bad dtype");
+  if (!G || !X || !dW || !workspace) return fail(JSPSR_EINVAL, "conv2d_wgrad: null pointer");
+  const int epc = dtype == JSPSR_F32 ? 4 : 8;
+  if (Cg <= 0 || Cx <= 0 || Cg % epc || Cx % epc || g_cstride % epc || g_coff % epc || x_cstride % epc || x_coff % epc ||
+      g_cstride < g_coff + Cg || x_cstride < x_coff + Cx)
+    return fail(JSPSR_EINVAL, "conv2d_wgrad: channel counts/pitches/offsets must be multiples of %d", epc);
+  if (R <= 0 || R > Cg || C <= 0 || C > Cx) return fail(JSPSR_EINVAL, "conv2d_wgrad: R/C exceed the padded channel counts");
+  if (B <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+    return fail(JSPSR_EINVAL, "conv2d_wgrad: bad geometry");
+  if (!aligned16(G) || !aligned16(X) || !aligned16(workspace)) return fail(JSPSR_EALIGN, "conv2d_wgrad: pointers must be 16-byte aligned");
+  WgradGeom g{};
+  g.B = B; g.OH = OH; g.OW = OW; g.Cg = Cg; g.g_cs = g_cstride; g.g_coff = g_coff;
+  g.IH = IH; g.IW = IW; g.Cx = Cx; g.x_cs = x_cstride; g.x_coff = x_coff;
+  g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.Ktot = KH * KW * Cx;
+  g.M = (long long)B * OH * OW;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  return dtype == JSPSR_F32 ? run<float>(G, X, dW, R, C, ws, g, accumulate, s)
+                            : run<__bf16>(G, X, dW, R, C, ws, g, accumulate, s);
+}

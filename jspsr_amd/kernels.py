@@ -82,3 +82,23 @@ def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None
                                       B, OH, OW, Cg, Cgs, g_coff, IH, IW, Cin, out.shape[3], out_coff,
                                       KH, KW, stride, pad, int(relu), _stream()), "jspsr_conv2d_dgrad")
     return out
+
+
+def conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=None, accumulate=False, g_coff=0, cg=None, x_coff=0, cx=None):
+    """dW (R,C,KH,KW) fp32 = sum_pixels G[.., r] * X[shifted.., c].  G (B,OH,OW,Cgs), X (B,IH,IW,Cxs) NHWC."""
+    _chk(G, "conv2d_wgrad")
+    _chk(X, "conv2d_wgrad")
+    B, OH, OW, Cgs = G.shape
+    _, IH, IW, Cxs = X.shape
+    cg = Cgs if cg is None else cg
+    cx = Cxs if cx is None else cx
+    if out is None:
+        out = torch.empty((R, C, KH, KW), dtype=torch.float32, device=G.device)
+    lib = _lib.load()
+    dt = _dt(G)
+    nbytes = lib.jspsr_conv2d_wgrad_workspace_bytes(dt, B, OH, OW, cg, cx, KH, KW)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=G.device)
+    _lib.check(lib.jspsr_conv2d_wgrad(dt, G.data_ptr(), cg, Cgs, g_coff, X.data_ptr(), cx, Cxs, x_coff,
+                                      out.data_ptr(), R, C, B, OH, OW, IH, IW, KH, KW, stride, pad,
+                                      int(accumulate), ws.data_ptr(), _stream()), "jspsr_conv2d_wgrad")
+    return out

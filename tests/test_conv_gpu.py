@@ -80,6 +80,41 @@ def test_conv_dgrad(dtype, B, H, W, Cin, Cout, k, stride, pad):
     assert _relerr(_nchw(dx.float()), x.grad) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", CASES + [(3, 40, 56, 4, 32, 5, 1, 2), (2, 64, 64, 64, 64, 3, 1, 1)])
+def test_conv_wgrad(dtype, B, H, W, Cin, Cout, k, stride, pad):
+    K = _k()
+    e = K.epc(dtype)
+    if Cin % e:
+        pytest.skip("channel granularity")
+    Cg = (Cout + e - 1) // e * e
+    g = torch.Generator().manual_seed(B * 31 + H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    go = torch.randn(B, Cout, OH, OW, generator=g)
+    if dtype == torch.bfloat16:
+        x, go = x.bfloat16().float(), go.bfloat16().float()
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, stride, pad).backward(go.double())
+    gop = F.pad(go, (0, 0, 0, 0, 0, Cg - Cout))
+    dW = K.conv2d_wgrad(_nhwc(gop).to(dtype), _nhwc(x).to(dtype), Cout, Cin, k, k, stride, pad)
+    assert dW.shape == (Cout, Cin, k, k) and dW.dtype == torch.float32
+    tol = 3e-6 if dtype == torch.float32 else 1e-5  # same (rounded) operands, fp32 accumulation both ways
+    assert _relerr(dW.cpu(), w.grad) < tol
+
+
+def test_conv_transpose_wgrad():
+    """ConvTranspose2d weight (I,O,kh,kw): G = its input, X = grad of its output."""
+    K = _k()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 64, 12, 10, generator=g)
+    gy = torch.randn(2, 32, 24, 20, generator=g)
+    w = torch.zeros(64, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(x.double(), w, None, 2, 1, 1).backward(gy.double())
+    dW = K.conv2d_wgrad(_nhwc(x), _nhwc(gy), 64, 32, 3, 3, 2, 1)
+    assert _relerr(dW.cpu(), w.grad) < 3e-6
+
+
 @pytest.mark.parametrize("C", [64, 256])
 def test_conv_transpose_forward(C):
     """ConvTranspose2d k3 s2 p1 op1 (basics.py:69-77) == dgrad launch with the (I,O,KH,KW) weight."""
