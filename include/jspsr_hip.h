@@ -119,6 +119,54 @@ int jspsr_conv2d_wgrad(int dtype, const void* G, int Cg, int g_cstride, int g_co
                        int IH, int IW, int KH, int KW, int stride, int pad, int accumulate,
                        void* workspace, jspsr_stream_t stream);
 
+/* ---- K4/K5: per-channel operators around the convolutions (HBM-bound, NHWC) -----------------
+ * Tensors are (pointer, channel pitch, channel offset) slices of NHWC buffers, `npix` pixels,
+ * `C` channels (multiple of 4 for fp32 / 8 for bf16); statistics and parameters are fp32.
+ * workspace: jspsr_reduce_workspace_bytes(dtype, C, nseg) bytes, 16-byte aligned
+ * (nseg = 1, or the batch size for the per-image gate kernels).
+ */
+size_t jspsr_reduce_workspace_bytes(int dtype, int C, int nseg);
+
+/* nn.BatchNorm2d forward fused with the residual add and ReLU of BasicBlock
+ * (models/components/basics.py:49-53,81-85,111-123):
+ *   y = [relu]( bn(x) * res_scale + res )      (res may be NULL)
+ * training != 0: batch statistics (biased var), running stats updated in place with `momentum`
+ * (unbiased var), save_mean / save_invstd [C] written for the backward.  training == 0: running
+ * stats are used (and copied to save_*). */
+int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, const void* res, int r_cs, int r_coff,
+                     void* y, int y_cs, int y_coff, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int training,
+                     int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
+                     void* workspace, jspsr_stream_t stream);
+
+/* Backward of the above.  dy is the gradient w.r.t. y; y is only read when relu != 0 (mask y > 0).
+ * dx (dense, pitch C) = grad w.r.t. x; dres (dense, may be NULL) = grad w.r.t. res;
+ * dgamma, dbeta [C] overwritten. */
+int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
+                      const void* x, int x_cs, int x_coff, const float* gamma, const float* save_mean,
+                      const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
+                      float* dgamma, float* dbeta, long long npix, int C, void* workspace,
+                      jspsr_stream_t stream);
+
+/* Backward of the conv epilogue `y = [relu](conv + bias)` of the BN-free Basic2d (basics.py:36-53):
+ * dz = dy * [y > 0] (written with pitch dz_cs if dz != NULL), dbias[c] = sum dz (if dbias != NULL). */
+int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int relu, void* dz,
+                       int dz_cs, float* dbias, long long npix, int C, void* workspace, jspsr_stream_t stream);
+
+/* ChannelAttention (models/components/resnet_cbam.py:36-53; applied in basics.py:57-58).
+ * gate_pool: avg[b,c], mx[b,c] over the npix pixels of image b, amax = smallest pixel index of the
+ * max.  gate_scale: y = x * s[b,c].  Backward: ds[b,c] = sum_p dy*x (reduce), then
+ * dx = dy*s + davg/npix + [p == amax] dmax (apply).  The C -> C/16 -> C MLP between pool and
+ * scale works on B x C vectors and stays on the host side of the ABI. */
+int jspsr_gate_pool(int dtype, const void* x, int B, long long npix, int C, float* avg, float* mx, int* amax,
+                    void* workspace, jspsr_stream_t stream);
+int jspsr_gate_scale(int dtype, const void* x, const float* s, void* y, int B, long long npix, int C,
+                     jspsr_stream_t stream);
+int jspsr_gate_backward_reduce(int dtype, const void* dy, const void* x, float* ds, int B, long long npix, int C,
+                               void* workspace, jspsr_stream_t stream);
+int jspsr_gate_backward_apply(int dtype, const void* dy, const float* s, const float* davg, const float* dmax,
+                              const int* amax, void* dx, int B, long long npix, int C, jspsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ _lib = None
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_f = ctypes.c_float
+c_ll = ctypes.c_longlong
 
 # name -> (restype, argtypes); must list every symbol include/jspsr_hip.h declares
 SIGNATURES = {
@@ -33,6 +34,16 @@ SIGNATURES = {
     "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p]),
     "jspsr_conv2d_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i] * 8),
     "jspsr_conv2d_wgrad": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p, c_p]),
+    "jspsr_reduce_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "jspsr_bn_forward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
+                               c_i, c_f, c_p, c_p, c_ll, c_i, c_p, c_p]),
+    "jspsr_bn_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_f,
+                                c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_p]),
+    "jspsr_act_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_i, c_p, c_ll, c_i, c_p, c_p]),
+    "jspsr_gate_pool": (c_i, [c_i, c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "jspsr_gate_scale": (c_i, [c_i, c_p, c_p, c_p, c_i, c_ll, c_i, c_p]),
+    "jspsr_gate_backward_reduce": (c_i, [c_i, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p]),
+    "jspsr_gate_backward_apply": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p]),
 }
 
 

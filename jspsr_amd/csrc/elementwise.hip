@@ -1,0 +1,609 @@
+// K4/K5 -- the HBM-bound per-channel operators around the convolutions, NHWC, fp32 or bf16 storage
+// with fp32 arithmetic:
+//   * BatchNorm2d training/eval forward + backward, fused with ReLU and the residual add
+//     (reference: models/components/basics.py:49-53,81-85,105-123)
+//   * bias-less ReLU backward + bias gradient for the BN-free convs (basics.py:36-53)
+//   * ChannelAttention pooling / scaling and their backward (resnet_cbam.py:36-53, basics.py:57-58)
+//
+// All reductions over pixels use one scheme: a (64 x 4)-thread workgroup owns a chunk of pixels
+// and 64 channel groups (16 bytes of channels per lane -> every wave instruction reads whole
+// 1 KiB / 512 B runs of the NHWC rows), accumulates in registers, folds its 4 pixel lanes through
+// LDS and writes one partial row; a finalize kernel sums the partial rows in a fixed order (fp64)
+// -> bit-reproducible statistics, no atomics.
+#include "common.h"
+
+namespace {
+
+using namespace jspsr;
+
+constexpr int TX = 64, TY = 4;
+
+template <typename T> struct V;   // VEC channels per lane = 16 bytes
+template <> struct V<float> { static constexpr int N = 4; };
+template <> struct V<__bf16> { static constexpr int N = 8; };
+
+template <typename T, int N>
+struct Pack { T v[N]; };
+
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, float (&f)[V<T>::N]) {
+  constexpr int N = V<T>::N;
+  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+  if constexpr (sizeof(T) == 4) {
+    f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y); f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+  } else {
+    const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  (void)N;
+}
+
+__device__ __forceinline__ unsigned bf16_bits(float x) {  // round-to-nearest-even, NaN preserved
+  const __bf16 h = (__bf16)x;
+  return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float (&f)[V<T>::N]) {
+  uint4 raw;
+  if constexpr (sizeof(T) == 4) {
+    raw.x = __float_as_uint(f[0]); raw.y = __float_as_uint(f[1]); raw.z = __float_as_uint(f[2]); raw.w = __float_as_uint(f[3]);
+  } else {
+    raw.x = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
+    raw.y = bf16_bits(f[2]) | (bf16_bits(f[3]) << 16);
+    raw.z = bf16_bits(f[4]) | (bf16_bits(f[5]) << 16);
+    raw.w = bf16_bits(f[6]) | (bf16_bits(f[7]) << 16);
+  }
+  *reinterpret_cast<uint4*>(p) = raw;
+}
+
+struct Slice {  // a channel slice of an NHWC tensor
+  const void* p;
+  int cs, coff;
+};
+
+struct RedGeom {
+  long long npix;        // pixels reduced per segment
+  int nseg;              // independent segments (1 for BN, B for per-image pooling)
+  int C;                 // channels
+  int chunks;            // pixel chunks per segment
+  long long chunk_pix;   // pixels per chunk
+};
+
+// Generic per-channel reduction: F supplies K accumulators per channel.
+// partial layout: [seg][chunk][K][C]
+template <typename T, int K, typename F>
+__device__ __forceinline__ void reduce_pixels(const RedGeom& g, float* __restrict__ partial, F&& body) {
+  constexpr int N = V<T>::N;
+  __shared__ float red[TY][K][TX * N];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int cg = blockIdx.y * TX + tx;   // channel group
+  const int c = cg * N;
+  const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
+  float acc[K][N];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[k][i] = 0.f;
+  const long long p0 = chunk * g.chunk_pix;
+  const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
+  if (c < g.C)
+    for (long long p = p0 + ty; p < p1; p += TY) body((long long)seg * g.npix + p, c, acc);
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[ty][k][tx * N + i] = acc[k][i];
+  __syncthreads();
+  if (ty == 0 && c < g.C) {
+    float* dst = partial + ((size_t)blockIdx.x * K) * g.C + c;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int y = 0; y < TY; ++y) s += red[y][k][tx * N + i];
+        dst[(size_t)k * g.C + i] = s;
+      }
+  }
+}
+
+RedGeom make_red(long long npix, int nseg, int C, int vec) {
+  RedGeom g;
+  g.npix = npix; g.nseg = nseg; g.C = C;
+  const int gy = (C / vec + TX - 1) / TX;
+  long long want = 2048 / ((long long)gy * nseg);
+  if (want < 1) want = 1;
+  long long chunks = (npix + 63) / 64;  // >= 64 pixels per chunk
+  if (chunks > want) chunks = want;
+  if (chunks < 1) chunks = 1;
+  g.chunk_pix = (npix + chunks - 1) / chunks;
+  g.chunks = (int)((npix + g.chunk_pix - 1) / g.chunk_pix);
+  return g;
+}
+dim3 red_grid(const RedGeom& g, int vec) { return dim3(g.nseg * g.chunks, (g.C / vec + TX - 1) / TX); }
+
+// ---------------------------------------------------------------- BatchNorm forward
+template <typename T>
+__global__ __launch_bounds__(TX * TY) void bn_stats_kernel(const T* __restrict__ x, int cs, int coff, RedGeom g,
+                                                          float* __restrict__ partial) {
+  constexpr int N = V<T>::N;
+  reduce_pixels<T, 2>(g, partial, [&](long long pix, int c, float (&acc)[2][N]) {
+    float f[N];
+    load_vec<T>(x + (size_t)pix * cs + coff + c, f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { acc[0][i] += f[i]; acc[1][i] += f[i] * f[i]; }
+  });
+}
+
+// mean / biased var from the partial rows; running stats (momentum, unbiased var); scale/shift.
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, long long count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, int training, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s = 0.0, ss = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      s += (double)partial[((size_t)r * 2) * C + c];
+      ss += (double)partial[((size_t)r * 2 + 1) * C + c];
+    }
+    const double m = s / (double)count;
+    double v = ss / (double)count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (running_mean) {
+      const double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  save_mean[c] = mean;
+  save_invstd[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+}
+
+// y = [relu]( (x*scale + shift) * res_scale + res )
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int x_cs, int x_coff,
+                                                      const T* __restrict__ res, int r_cs, int r_coff,
+                                                      T* __restrict__ y, int y_cs, int y_coff,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      float res_scale, int relu, long long npix, int C) {
+  constexpr int N = V<T>::N;
+  const int groups = C / N;
+  const long long total = npix * groups;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / groups;
+    const int c = (int)(i % groups) * N;
+    float f[N], r[N];
+    load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, f);
+    if (res) load_vec<T>(res + (size_t)pix * r_cs + r_coff + c, r);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float v = f[k] * scale[c + k] + shift[c + k];
+      if (res) v = v * res_scale + r[k];
+      if (relu) v = fmaxf(v, 0.f);
+      f[k] = v;
+    }
+    store_vec<T>(y + (size_t)pix * y_cs + y_coff + c, f);
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm backward
+// dz = dy * (y > 0 if relu);  partial sums of dz and dz * xhat
+template <typename T>
+__global__ __launch_bounds__(TX * TY) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
+                                                               const T* __restrict__ y, int y_cs, int y_coff,
+                                                               const T* __restrict__ x, int x_cs, int x_coff,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, int relu, RedGeom g,
+                                                               float* __restrict__ partial) {
+  constexpr int N = V<T>::N;
+  reduce_pixels<T, 2>(g, partial, [&](long long pix, int c, float (&acc)[2][N]) {
+    float d[N], xv[N], yv[N];
+    load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
+    load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, xv);
+    if (relu) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float dz = (relu && !(yv[i] > 0.f)) ? 0.f : d[i];
+      acc[0][i] += dz;
+      acc[1][i] += dz * (xv[i] - mean[c + i]) * invstd[c + i];
+    }
+  });
+}
+
+// dbeta = sum dz ; dgamma = sum dz*xhat ; coefficients for the apply pass
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, long long count,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       int training, float res_scale, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s += (double)partial[((size_t)r * 2) * C + c];
+    sx += (double)partial[((size_t)r * 2 + 1) * C + c];
+  }
+  // the BN branch sees dz * res_scale
+  dbeta[c] = (float)(s * res_scale);
+  dgamma[c] = (float)(sx * res_scale);
+  const float k = gamma[c] * invstd[c] * res_scale;
+  coef[c] = k;                                                     // dx = k * (dz - a - xhat * b)
+  coef[C + c] = training ? (float)(s / (double)count) : 0.f;        // a = mean(dz)
+  coef[2 * C + c] = training ? (float)(sx / (double)count) : 0.f;   // b = mean(dz * xhat)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
+                                                          const T* __restrict__ y, int y_cs, int y_coff,
+                                                          const T* __restrict__ x, int x_cs, int x_coff,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ coef, int relu,
+                                                          T* __restrict__ dx, T* __restrict__ dres, long long npix, int C) {
+  constexpr int N = V<T>::N;
+  const int groups = C / N;
+  const long long total = npix * groups;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / groups;
+    const int c = (int)(i % groups) * N;
+    float d[N], xv[N], yv[N], o[N];
+    load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
+    load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, xv);
+    if (relu) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : d[k];
+      d[k] = dz;
+      const float xhat = (xv[k] - mean[c + k]) * invstd[c + k];
+      o[k] = coef[c + k] * (dz - coef[C + c + k] - xhat * coef[2 * C + c + k]);
+    }
+    store_vec<T>(dx + (size_t)pix * C + c, o);
+    if (dres) store_vec<T>(dres + (size_t)pix * C + c, d);
+  }
+}
+
+// ---------------------------------------------------------------- ReLU backward + bias gradient
+template <typename T>
+__global__ __launch_bounds__(TX * TY) void act_bwd_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
+                                                         const T* __restrict__ y, int relu, T* __restrict__ dz,
+                                                         int dz_cs, RedGeom g, float* __restrict__ partial) {
+  constexpr int N = V<T>::N;
+  reduce_pixels<T, 1>(g, partial, [&](long long pix, int c, float (&acc)[1][N]) {
+    float d[N], yv[N];
+    load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
+    if (relu) load_vec<T>(y + (size_t)pix * g.C + c, yv);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (relu && !(yv[i] > 0.f)) d[i] = 0.f;
+      acc[0][i] += d[i];
+    }
+    if (dz) store_vec<T>(dz + (size_t)pix * dz_cs + c, d);
+  });
+}
+
+__global__ void sum_rows_kernel(const float* __restrict__ partial, int rows, int K, int k, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)partial[((size_t)r * K + k) * C + c];
+  out[c] = (float)s;
+}
+
+// ---------------------------------------------------------------- ChannelAttention pieces
+// per image and channel: sum and max (+ smallest pixel index of the max)
+template <typename T>
+__global__ __launch_bounds__(TX * TY) void gate_pool_kernel(const T* __restrict__ x, RedGeom g,
+                                                           float* __restrict__ psum, float* __restrict__ pmax,
+                                                           int* __restrict__ pidx) {
+  constexpr int N = V<T>::N;
+  __shared__ float rs[TY][TX * N], rm[TY][TX * N];
+  __shared__ int ri[TY][TX * N];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c = (blockIdx.y * TX + tx) * N;
+  const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
+  float s[N], m[N];
+  int idx[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { s[i] = 0.f; m[i] = -INFINITY; idx[i] = 0x7fffffff; }
+  const long long p0 = chunk * g.chunk_pix;
+  const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
+  if (c < g.C)
+    for (long long p = p0 + ty; p < p1; p += TY) {
+      float f[N];
+      load_vec<T>(x + ((size_t)seg * g.npix + p) * g.C + c, f);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        s[i] += f[i];
+        if (f[i] > m[i]) { m[i] = f[i]; idx[i] = (int)p; }
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { rs[ty][tx * N + i] = s[i]; rm[ty][tx * N + i] = m[i]; ri[ty][tx * N + i] = idx[i]; }
+  __syncthreads();
+  if (ty == 0 && c < g.C) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float ss = 0.f, mm = -INFINITY;
+      int ii = 0x7fffffff;
+#pragma unroll
+      for (int y = 0; y < TY; ++y) {
+        ss += rs[y][tx * N + i];
+        const float v = rm[y][tx * N + i];
+        const int j = ri[y][tx * N + i];
+        if (v > mm || (v == mm && j < ii)) { mm = v; ii = j; }
+      }
+      const size_t o = (size_t)blockIdx.x * g.C + c + i;
+      psum[o] = ss; pmax[o] = mm; pidx[o] = ii;
+    }
+  }
+}
+
+__global__ void gate_pool_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ pmax,
+                                          const int* __restrict__ pidx, int chunks, int C, long long npix,
+                                          float* __restrict__ avg, float* __restrict__ mx, int* __restrict__ amax) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  double s = 0.0;
+  float m = -INFINITY;
+  int ii = 0x7fffffff;
+  for (int r = 0; r < chunks; ++r) {
+    const size_t o = ((size_t)b * chunks + r) * C + c;
+    s += (double)psum[o];
+    if (pmax[o] > m || (pmax[o] == m && pidx[o] < ii)) { m = pmax[o]; ii = pidx[o]; }
+  }
+  avg[(size_t)b * C + c] = (float)(s / (double)npix);
+  mx[(size_t)b * C + c] = m;
+  amax[(size_t)b * C + c] = ii;
+}
+
+// y[b,p,c] = x[b,p,c] * s[b,c]
+template <typename T>
+__global__ __launch_bounds__(256) void gate_scale_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                        T* __restrict__ y, long long npix, int C, int B) {
+  constexpr int N = V<T>::N;
+  const int groups = C / N;
+  const long long total = (long long)B * npix * groups;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / groups;
+    const int c = (int)(i % groups) * N;
+    const int b = (int)(pix / npix);
+    float f[N];
+    load_vec<T>(x + (size_t)pix * C + c, f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) f[k] *= s[(size_t)b * C + c + k];
+    store_vec<T>(y + (size_t)pix * C + c, f);
+  }
+}
+
+// ds[b,c] = sum_p dy*x
+template <typename T>
+__global__ __launch_bounds__(TX * TY) void gate_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                 RedGeom g, float* __restrict__ partial) {
+  constexpr int N = V<T>::N;
+  reduce_pixels<T, 1>(g, partial, [&](long long pix, int c, float (&acc)[1][N]) {
+    float d[N], xv[N];
+    load_vec<T>(dy + (size_t)pix * g.C + c, d);
+    load_vec<T>(x + (size_t)pix * g.C + c, xv);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[0][i] += d[i] * xv[i];
+  });
+}
+
+__global__ void gate_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ ds) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < chunks; ++r) s += (double)partial[((size_t)b * chunks + r) * C + c];
+  ds[(size_t)b * C + c] = (float)s;
+}
+
+// dx = dy*s + davg/npix + [p == argmax] dmax
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ s,
+                                                            const float* __restrict__ davg, const float* __restrict__ dmax,
+                                                            const int* __restrict__ amax, T* __restrict__ dx,
+                                                            long long npix, int C, int B) {
+  constexpr int N = V<T>::N;
+  const int groups = C / N;
+  const long long total = (long long)B * npix * groups;
+  const float inv = 1.f / (float)npix;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i / groups;
+    const int c = (int)(i % groups) * N;
+    const int b = (int)(pix / npix);
+    const int p = (int)(pix - (long long)b * npix);
+    float f[N];
+    load_vec<T>(dy + (size_t)pix * C + c, f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const size_t o = (size_t)b * C + c + k;
+      f[k] = f[k] * s[o] + davg[o] * inv + (amax[o] == p ? dmax[o] : 0.f);
+    }
+    store_vec<T>(dx + (size_t)pix * C + c, f);
+  }
+}
+
+int ew_blocks(long long total) {
+  long long b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int check_c(int dtype, int C, const char* what) {
+  if (dtype != JSPSR_F32 && dtype != JSPSR_BF16) return fail(JSPSR_EINVAL, "%s: bad dtype", what);
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  if (C <= 0 || C % vec) return fail(JSPSR_EINVAL, "%s: C=%d must be a multiple of %d", what, C, vec);
+  return JSPSR_OK;
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, CALL)                    \
+  do {                                           \
+    if ((dtype) == JSPSR_F32) { using T = float; CALL; } else { using T = __bf16; CALL; } \
+  } while (0)
+
+extern "C" size_t jspsr_reduce_workspace_bytes(int dtype, int C, int nseg) {
+  if (C <= 0 || nseg <= 0) return 0;
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  const RedGeom g = make_red(1LL << 40, nseg, C, vec);  // the most chunks any pixel count can get
+  const size_t rows = (size_t)nseg * g.chunks;
+  return (rows * 3 + 4) * (size_t)C * sizeof(float) + 64;
+}
+
+extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, const void* res, int r_cs, int r_coff,
+                                void* y, int y_cs, int y_coff, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int training,
+                                int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
+                                void* workspace, jspsr_stream_t stream) {
+  if (int e = check_c(dtype, C, "bn_forward")) return e;
+  if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || npix <= 0)
+    return fail(JSPSR_EINVAL, "bn_forward: null pointer or empty tensor");
+  if (!training && (!running_mean || !running_var)) return fail(JSPSR_EINVAL, "bn_forward: eval mode needs running stats");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  if (x_cs % vec || x_coff % vec || y_cs % vec || y_coff % vec || (res && (r_cs % vec || r_coff % vec)))
+    return fail(JSPSR_EINVAL, "bn_forward: channel pitches/offsets must be multiples of %d", vec);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  float* scale = ws;
+  float* shift = ws + C;
+  float* partial = ws + 2 * C;
+  int rows = 0;
+  if (training) {
+    const RedGeom g = make_red(npix, 1, C, vec);
+    rows = g.chunks;
+    DISPATCH(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
+                                       static_cast<const T*>(x), x_cs, x_coff, g, partial));
+    if (int e = check_launch("bn_stats")) return e;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, rows, C, npix, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, save_mean, save_invstd, scale, shift);
+  if (int e = check_launch("bn_finalize")) return e;
+  DISPATCH(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_blocks(npix * (C / vec))), dim3(256), 0, s,
+                                     static_cast<const T*>(x), x_cs, x_coff, static_cast<const T*>(res), r_cs, r_coff,
+                                     static_cast<T*>(y), y_cs, y_coff, scale, shift, res_scale, relu, npix, C));
+  return check_launch("bn_apply");
+}
+
+extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
+                                 const void* x, int x_cs, int x_coff, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
+                                 float* dgamma, float* dbeta, long long npix, int C, void* workspace,
+                                 jspsr_stream_t stream) {
+  if (int e = check_c(dtype, C, "bn_backward")) return e;
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || npix <= 0 || (relu && !y))
+    return fail(JSPSR_EINVAL, "bn_backward: null pointer or empty tensor");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  if (dy_cs % vec || dy_coff % vec || x_cs % vec || x_coff % vec || (relu && (y_cs % vec || y_coff % vec)))
+    return fail(JSPSR_EINVAL, "bn_backward: channel pitches/offsets must be multiples of %d", vec);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* ws = static_cast<float*>(workspace);
+  float* coef = ws;
+  float* partial = ws + 3 * C;
+  const RedGeom g = make_red(npix, 1, C, vec);
+  DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
+                                     static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
+                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, relu, g, partial));
+  if (int e = check_launch("bn_bwd_reduce")) return e;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, g.chunks, C, npix, gamma,
+                     save_invstd, training, res_scale, dgamma, dbeta, coef);
+  if (int e = check_launch("bn_bwd_finalize")) return e;
+  DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(npix * (C / vec))), dim3(256), 0, s,
+                                     static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
+                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, coef, relu,
+                                     static_cast<T*>(dx), static_cast<T*>(dres), npix, C));
+  return check_launch("bn_bwd_apply");
+}
+
+extern "C" int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int relu, void* dz,
+                                  int dz_cs, float* dbias, long long npix, int C, void* workspace, jspsr_stream_t stream) {
+  if (int e = check_c(dtype, C, "act_backward")) return e;
+  if (!dy || (relu && !y) || !workspace || npix <= 0) return fail(JSPSR_EINVAL, "act_backward: null pointer or empty tensor");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  if (dy_cs % vec || dy_coff % vec || (dz && dz_cs % vec)) return fail(JSPSR_EINVAL, "act_backward: bad pitch");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  const RedGeom g = make_red(npix, 1, C, vec);
+  DISPATCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s, static_cast<const T*>(dy),
+                                     dy_cs, dy_coff, static_cast<const T*>(y), relu, static_cast<T*>(dz), dz_cs, g, partial));
+  if (int e = check_launch("act_backward")) return e;
+  if (dbias) {
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, g.chunks, 1, 0, C, dbias);
+    return check_launch("act_backward_bias");
+  }
+  return JSPSR_OK;
+}
+
+extern "C" int jspsr_gate_pool(int dtype, const void* x, int B, long long npix, int C, float* avg, float* mx, int* amax,
+                               void* workspace, jspsr_stream_t stream) {
+  if (int e = check_c(dtype, C, "gate_pool")) return e;
+  if (!x || !avg || !mx || !amax || !workspace || B <= 0 || npix <= 0 || npix > 0x7fffffffLL)
+    return fail(JSPSR_EINVAL, "gate_pool: bad arguments");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const RedGeom g = make_red(npix, B, C, vec);
+  const size_t rows = (size_t)B * g.chunks;
+  float* psum = static_cast<float*>(workspace);
+  float* pmax = psum + rows * C;
+  int* pidx = reinterpret_cast<int*>(pmax + rows * C);
+  DISPATCH(dtype, hipLaunchKernelGGL(gate_pool_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s, static_cast<const T*>(x), g,
+                                     psum, pmax, pidx));
+  if (int e = check_launch("gate_pool")) return e;
+  hipLaunchKernelGGL(gate_pool_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, psum, pmax, pidx, g.chunks, C,
+                     npix, avg, mx, amax);
+  return check_launch("gate_pool_finalize");
+}
+
+extern "C" int jspsr_gate_scale(int dtype, const void* x, const float* s_, void* y, int B, long long npix, int C,
+                                jspsr_stream_t stream) {
+  if (int e = check_c(dtype, C, "gate_scale")) return e;
+  if (!x || !s_ || !y || B <= 0 || npix <= 0) return fail(JSPSR_EINVAL, "gate_scale: bad arguments");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH(dtype, hipLaunchKernelGGL(gate_scale_kernel<T>, dim3(ew_blocks((long long)B * npix * (C / vec))), dim3(256), 0, s,
+                                     static_cast<const T*>(x), s_, static_cast<T*>(y), npix, C, B));
+  return check_launch("gate_scale");
+}
+
+extern "C" int jspsr_gate_backward_reduce(int dtype, const void* dy, const void* x, float* ds, int B, long long npix, int C,
+                                          void* workspace, jspsr_stream_t stream) {
+  if (int e = check_c(dtype, C, "gate_backward_reduce")) return e;
+  if (!dy || !x || !ds || !workspace || B <= 0 || npix <= 0) return fail(JSPSR_EINVAL, "gate_backward_reduce: bad arguments");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const RedGeom g = make_red(npix, B, C, vec);
+  float* partial = static_cast<float*>(workspace);
+  DISPATCH(dtype, hipLaunchKernelGGL(gate_bwd_reduce_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
+                                     static_cast<const T*>(dy), static_cast<const T*>(x), g, partial));
+  if (int e = check_launch("gate_backward_reduce")) return e;
+  hipLaunchKernelGGL(gate_bwd_finalize_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, partial, g.chunks, C, ds);
+  return check_launch("gate_backward_finalize");
+}
+
+extern "C" int jspsr_gate_backward_apply(int dtype, const void* dy, const float* s_, const float* davg, const float* dmax,
+                                         const int* amax, void* dx, int B, long long npix, int C, jspsr_stream_t stream) {
+  if (int e = check_c(dtype, C, "gate_backward_apply")) return e;
+  if (!dy || !s_ || !davg || !dmax || !amax || !dx || B <= 0 || npix <= 0)
+    return fail(JSPSR_EINVAL, "gate_backward_apply: bad arguments");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH(dtype, hipLaunchKernelGGL(gate_bwd_apply_kernel<T>, dim3(ew_blocks((long long)B * npix * (C / vec))), dim3(256), 0,
+                                     s, static_cast<const T*>(dy), s_, davg, dmax, amax, static_cast<T*>(dx), npix, C, B));
+  return check_launch("gate_backward_apply");
+}

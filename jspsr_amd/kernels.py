@@ -102,3 +102,128 @@ def conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=None, accumulate=False, g_
                                       out.data_ptr(), R, C, B, OH, OW, IH, IW, KH, KW, stride, pad,
                                       int(accumulate), ws.data_ptr(), _stream()), "jspsr_conv2d_wgrad")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# per-channel operators (elementwise.hip)
+# ---------------------------------------------------------------------------------------------
+
+_ws_cache = {}
+
+
+def _workspace(dtype_code: int, C: int, nseg: int, device) -> torch.Tensor:
+    """Scratch for the reduction kernels; cached per (stream, size class) -- stream-ordered reuse."""
+    lib = _lib.load()
+    n = lib.jspsr_reduce_workspace_bytes(dtype_code, C, nseg)
+    key = (device, _stream())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu=False, res=None,
+               res_scale=1.0, out=None, out_coff=0):
+    """x (B,H,W,C) -> y = [relu](bn(x)*res_scale + res); returns (y, save_mean, save_invstd)."""
+    _chk(x, "bn_forward")
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    dt = _dt(x)
+    ws = _workspace(dt, C, 1, x.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_bn_forward(dt, x.data_ptr(), C, 0, res.data_ptr() if res is not None else None,
+                                    res.shape[3] if res is not None else 0, 0, out.data_ptr(), out.shape[3], out_coff,
+                                    gamma.data_ptr(), beta.data_ptr(),
+                                    running_mean.data_ptr() if running_mean is not None else None,
+                                    running_var.data_ptr() if running_var is not None else None,
+                                    float(momentum), float(eps), int(training), int(relu), float(res_scale),
+                                    mean.data_ptr(), invstd.data_ptr(), B * H * W, C, ws.data_ptr(), _stream()),
+               "jspsr_bn_forward")
+    return out, mean, invstd
+
+
+def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False):
+    """-> (dx, dres or None, dgamma, dbeta)."""
+    _chk(dy, "bn_backward")
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    dt = _dt(x)
+    ws = _workspace(dt, C, 1, x.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_bn_backward(dt, dy.data_ptr(), dy.shape[3], 0, y.data_ptr() if y is not None else None,
+                                     y.shape[3] if y is not None else 0, 0, x.data_ptr(), C, 0, gamma.data_ptr(),
+                                     mean.data_ptr(), invstd.data_ptr(), int(training), int(relu), float(res_scale),
+                                     dx.data_ptr(), dres.data_ptr() if dres is not None else None, dgamma.data_ptr(),
+                                     dbeta.data_ptr(), B * H * W, C, ws.data_ptr(), _stream()), "jspsr_bn_backward")
+    return dx, dres, dgamma, dbeta
+
+
+def act_backward(dy, y, relu, want_dz=True, want_dbias=True, dz_channels=None):
+    """dz = dy*[y>0] (optionally into a wider, zero-initialised channel pitch), dbias = sum dz."""
+    _chk(dy, "act_backward")
+    B, H, W, C = dy.shape
+    dz = None
+    if want_dz:
+        cz = C if dz_channels is None else dz_channels
+        dz = torch.empty((B, H, W, cz), dtype=dy.dtype, device=dy.device) if cz == C else \
+            torch.zeros((B, H, W, cz), dtype=dy.dtype, device=dy.device)
+    dbias = torch.empty(C, dtype=torch.float32, device=dy.device) if want_dbias else None
+    dt = _dt(dy)
+    ws = _workspace(dt, C, 1, dy.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_act_backward(dt, dy.data_ptr(), C, 0, y.data_ptr() if y is not None else None, int(relu),
+                                      dz.data_ptr() if dz is not None else None, dz.shape[3] if dz is not None else 0,
+                                      dbias.data_ptr() if dbias is not None else None, B * H * W, C, ws.data_ptr(),
+                                      _stream()), "jspsr_act_backward")
+    return dz, dbias
+
+
+def gate_pool(x):
+    _chk(x, "gate_pool")
+    B, H, W, C = x.shape
+    avg = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    mx = torch.empty_like(avg)
+    amax = torch.empty((B, C), dtype=torch.int32, device=x.device)
+    dt = _dt(x)
+    ws = _workspace(dt, C, B, x.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_gate_pool(dt, x.data_ptr(), B, H * W, C, avg.data_ptr(), mx.data_ptr(), amax.data_ptr(),
+                                   ws.data_ptr(), _stream()), "jspsr_gate_pool")
+    return avg, mx, amax
+
+
+def gate_scale(x, s):
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_gate_scale(_dt(x), x.data_ptr(), s.data_ptr(), y.data_ptr(), B, H * W, C, _stream()),
+               "jspsr_gate_scale")
+    return y
+
+
+def gate_backward_reduce(dy, x):
+    B, H, W, C = x.shape
+    ds = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    dt = _dt(x)
+    ws = _workspace(dt, C, B, x.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_gate_backward_reduce(dt, dy.data_ptr(), x.data_ptr(), ds.data_ptr(), B, H * W, C,
+                                              ws.data_ptr(), _stream()), "jspsr_gate_backward_reduce")
+    return ds
+
+
+def gate_backward_apply(dy, s, davg, dmax, amax):
+    B, H, W, C = dy.shape
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_gate_backward_apply(_dt(dy), dy.data_ptr(), s.data_ptr(), davg.data_ptr(), dmax.data_ptr(),
+                                             amax.data_ptr(), dx.data_ptr(), B, H * W, C, _stream()),
+               "jspsr_gate_backward_apply")
+    return dx
