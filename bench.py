@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=TILES_PER_GPU, help="tiles per GPU")
+    ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
+                    help="activation storage / MFMA operand type (BASELINE config 3 names bf16); "
+                         "accumulation, BN statistics, K1 and master weights are fp32 either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -166,6 +169,7 @@ def main():
     np.random.seed(0)
     torch.manual_seed(0)
     model = Model(in_channels=IN_CHANNELS, out_channels=1, num_feature=32, layers=(2, 2, 2, 2), spn=True).to(device).train()
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     broadcast_module(model)
     reducer = GradReducer(model.parameters())
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-6, fused=True)  # configs/*.yml:71-76
@@ -220,7 +224,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": "jspsr_r8_img_msk (image+mask guided, 43.87M params), "

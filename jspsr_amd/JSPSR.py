@@ -29,6 +29,7 @@ class Model(nn.Module):
         self.out_channels = out_channels
         self.spn = spn
         self.spn_scale = spn_scale
+        self.compute_dtype = torch.float32  # or torch.bfloat16: bf16 storage, fp32 accumulate/statistics
         assert len(in_channels) > 1, "At least 2 input data are required"
         if not spn:
             raise NotImplementedError("spn=False (plain conv head) is outside the hot path")
@@ -124,11 +125,16 @@ class Model(nn.Module):
         dem, img, msk, canopy, coord = self.parse_input(
             self.flag_dem_img, self.flag_dem_msk, self.flag_dem_canopy, self.flag_dem_coord, *in_tensor)
         aux = msk if msk is not None else (canopy if canopy is not None else coord)
-        feats = {"dem": self.conv_dem(dem)}
+        with E.compute_dtype(self.compute_dtype):
+            return self._forward(dem, img, aux)
+
+    def _forward(self, dem, img, aux):
+        dem_a = E.from_nchw(dem)
+        feats = {"dem": self.conv_dem(dem_a)}
         if img is not None:
-            feats["img"] = self.conv_img(img)
+            feats["img"] = self.conv_img(E.from_nchw(img))
         if aux is not None:
-            feats["aux"] = self.conv_aux(aux)
+            feats["aux"] = self.conv_aux(E.from_nchw(aux))
         order = [b for b in self._branches if b in feats]
         if len(order) < 2:
             raise NotImplementedError
@@ -145,5 +151,6 @@ class Model(nn.Module):
             x = E.cat((up(x), skip))  # :354-368
         c0 = self.conv0(x)
         dem = dem.detach()  # :372
-        weight, off16 = self.generator.heads(self.generator.features(dem, c0))
-        return self.postprocessor(dem, weight, off16)  # 16-channel offsets: centre pair is implicit
+        weight, off16 = self.generator.heads(self.generator.features(dem_a.detach(), c0))
+        # K1 reads planar fp32 operands; 16-channel offsets: the zero centre pair is implicit
+        return self.postprocessor(dem.float(), E.to_nchw_f32(weight), E.to_nchw_f32(off16))

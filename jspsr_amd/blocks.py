@@ -44,10 +44,10 @@ class ConvUnit(nn.Module):
         if hasattr(self, "camb"):
             x = self.camb(x)
         c = self.conv[0]
-        y = E.conv2d(x, c.weight, c.bias, 1, self.k // 2)
         if hasattr(self.conv, "bn"):
+            y = E.conv2d(x, c.weight, None, 1, self.k // 2)
             return E.batch_norm(y, self.conv.bn, relu=self.relu)
-        return E.bias_act(y, self.relu)
+        return E.conv2d(x, c.weight, c.bias, 1, self.k // 2, relu=self.relu)  # bias + ReLU in the epilogue
 
 
 class UpUnit(nn.Module):

@@ -1,18 +1,36 @@
-"""Layer-level operators of the hot path, all on the GPU.
+"""Layer-level operators of the hot path.  Every one of them runs HIP kernels from
+libjspsr_hip.so (jspsr_amd.ops / jspsr_amd.kernels); there is no CPU or eager fallback.
 
-Activations are torch tensors of logical shape (B,C,H,W) held in channels-last memory (NHWC):
-the layout the implicit-GEMM kernels consume.  One-channel tensors are identical in both
-layouts, so the module boundary (reference: contiguous NCHW fp32, utils/utils.py:156-179)
-needs no conversion for the DEM and the output.
+Activations travel as NHWC tensors (B, H, W, C) in the compute dtype (fp32, or bf16 storage with
+fp32 accumulation and fp32 statistics).  The module boundary is the reference's: contiguous fp32
+NCHW tensors on the device (utils/utils.py:156-179); one-channel tensors are identical in both
+layouts, so the DEM and the output need no conversion.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
+from . import kernels as K
 from . import ops
 
-CL = torch.channels_last
+_compute_dtype = torch.float32
+
+
+class compute_dtype:
+    """Context manager: storage dtype of activations (torch.float32 or torch.bfloat16)."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _compute_dtype
+        self.prev, _compute_dtype = _compute_dtype, self.dtype
+
+    def __exit__(self, *a):
+        global _compute_dtype
+        _compute_dtype = self.prev
 
 
 def _gpu(x: torch.Tensor) -> torch.Tensor:
@@ -22,43 +40,47 @@ def _gpu(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def to_nhwc(x: torch.Tensor) -> torch.Tensor:
-    return _gpu(x).contiguous(memory_format=CL)
+def from_nchw(x: torch.Tensor) -> torch.Tensor:
+    """Boundary tensor (B,C,H,W) fp32 -> NHWC activations in the compute dtype, channel-padded."""
+    _gpu(x)
+    B, C, H, W = x.shape
+    x = x.reshape(B, H, W, 1) if C == 1 else x.permute(0, 2, 3, 1)
+    return ops.pad_channels(x.to(_compute_dtype), K.epc(_compute_dtype)).contiguous()
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0):
-    return F.conv2d(to_nhwc(x), weight, bias, stride, padding)
+def to_nchw_f32(x: torch.Tensor) -> torch.Tensor:
+    """NHWC activations -> planar fp32 (B,C,H,W) (what K1 and the caller consume)."""
+    B, H, W, C = x.shape
+    if C == 1:
+        return x.float().reshape(B, 1, H, W)
+    return x.permute(0, 3, 1, 2).float().contiguous()
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
+    return ops.conv2d(x, weight, bias, stride, padding, relu)
 
 
 def conv_transpose2d(x, weight):
     """ConvTranspose2d k3 s2 p1 op1, no bias (basics.py:69-77)."""
-    return F.conv_transpose2d(to_nhwc(x), weight, None, 2, 1, 1)
+    return ops.conv_transpose2d(x, weight)
 
 
 def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, res_scale=1.0):
     """BatchNorm2d (+ `* res_scale + residual`) (+ ReLU): basics.py:113-123."""
+    training = bn.training or bn.running_mean is None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
-    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
-    if residual is not None:
-        y = y * res_scale + residual if res_scale != 1.0 else y + residual
-    return F.relu(y) if relu else y
-
-
-def bias_act(x, relu=True):
-    return F.relu(x) if relu else x
+    return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training,
+                          relu, residual, res_scale)
 
 
 def channel_gate(x, w1, w2):
     """x * sigmoid(MLP(avgpool x) + MLP(maxpool x)), resnet_cbam.py:49-53 + basics.py:57-58."""
-    avg = x.mean((2, 3), keepdim=True)
-    mx = x.amax((2, 3), keepdim=True)
-    mlp = lambda v: F.conv2d(F.relu(F.conv2d(v, w1)), w2)
-    return x * torch.sigmoid(mlp(avg) + mlp(mx))
+    return ops.channel_gate(x, w1, w2)
 
 
 def cat(tensors):
-    return torch.cat(tensors, 1)
+    return torch.cat(tuple(tensors), 3)
 
 
 def sigmoid(x):
@@ -66,5 +88,5 @@ def sigmoid(x):
 
 
 def propagate(dem, weight, offset, w, b, scale=1.0):
-    """K1 wants planar (NCHW) weight / offset: one coalesced stream per tap plane."""
+    """K1: planar fp32 operands, one coalesced stream per tap plane."""
     return ops.propagate(dem.contiguous(), weight.contiguous(), offset.contiguous(), w, b, scale)

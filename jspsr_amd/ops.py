@@ -71,3 +71,159 @@ def propagate(dem, weight, offset, w, b, scale: float = 1.0):
     (the reference detaches it: models/JSPSR.py:372).
     """
     return _Propagate.apply(dem, weight, offset, w, b, scale)
+
+
+# =============================================================================================
+# NHWC layer operators: torch.autograd.Function shells around jspsr_amd.kernels (HIP).
+# Tensors are (B, H, W, C) contiguous, fp32 or bf16; parameters stay fp32 masters.
+# =============================================================================================
+from . import kernels as K  # noqa: E402
+
+
+def pad_channels(x: torch.Tensor, mult: int) -> torch.Tensor:
+    """Zero-pad the channel (last) dim to a multiple of `mult` (16-byte chunks for the gathers)."""
+    c = x.shape[-1]
+    p = (-c) % mult
+    return x if p == 0 else torch.nn.functional.pad(x, (0, p))
+
+
+class _Conv(torch.autograd.Function):
+    """nn.Conv2d (basics.py:11-20,39-47) or nn.ConvTranspose2d k3 s2 p1 op1 (basics.py:69-77),
+    with the bias + ReLU of a BN-free Basic2d fused into the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu, transposed):
+        x = x.contiguous()
+        cdt = x.dtype
+        e = K.epc(cdt)
+        B, H, W, Cp = x.shape
+        if Cp % e:
+            raise ValueError(f"conv: input channels {Cp} must be padded to a multiple of {e} (ops.pad_channels)")
+        w = weight.detach().contiguous()
+        bias_d = bias.detach().contiguous() if bias is not None else None
+        if not transposed:
+            O, I, KH, KW = w.shape
+            if Cp < I:
+                raise ValueError("conv: input has fewer channels than the weight")
+            y = K.conv2d_forward(x, K.pack_weight(w, 0, Cp, cdt), bias_d, stride, pad, relu)
+        else:
+            I, O, KH, KW = w.shape  # ConvTranspose2d weight layout
+            if Cp != I or stride != 2 or pad != 1 or KH != 3:
+                raise ValueError("conv_transpose: only k3 s2 p1 op1 without channel padding is built")
+            y = K.conv2d_dgrad(x, K.pack_weight(w, 1, Cp, cdt), (2 * H, 2 * W), 2, 1, bias=bias_d, relu=relu)
+        ctx.cfg = (stride, pad, relu, transposed, bias is not None)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, relu, transposed, has_bias = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        cdt = x.dtype
+        e = K.epc(cdt)
+        dy = dy.contiguous()
+        Co = dy.shape[3]
+        Cg = (Co + e - 1) // e * e
+        dbias = None
+        if Co % e == 0 and (relu or has_bias):
+            dz, dbias = K.act_backward(dy, y, relu, want_dz=relu, want_dbias=has_bias)
+            if dz is None:
+                dz = dy
+        else:  # tiny heads (9 channels): host-side glue on (B,H,W,9)
+            dz = dy * (y > 0) if relu else dy
+            if has_bias:
+                dbias = dz.float().sum((0, 1, 2))
+            dz = pad_channels(dz, e).contiguous()
+        B, H, W, Cp = x.shape
+        dx = dW = None
+        if not transposed:
+            O, I, KH, KW = w.shape
+            if ctx.needs_input_grad[0]:
+                if Cp != I:
+                    raise RuntimeError("conv backward: gradient w.r.t. a channel-padded input is not supported")
+                dx = K.conv2d_dgrad(dz, K.pack_weight(w, 1, Cg, cdt), (H, W), stride, pad)
+            if ctx.needs_input_grad[1]:
+                dW = K.conv2d_wgrad(dz, x, O, I, KH, KW, stride, pad)
+        else:
+            I, O, KH, KW = w.shape
+            if ctx.needs_input_grad[0]:
+                # d/dx of a transposed conv = ordinary stride-2 conv of the fine-grid gradient
+                dx = K.conv2d_forward(dz, K.pack_weight(w, 0, Cg, cdt), None, 2, 1, False)
+            if ctx.needs_input_grad[1]:
+                dW = K.conv2d_wgrad(x, dz, I, O, KH, KW, 2, 1)
+        return dx, dW, dbias, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
+    return _Conv.apply(x, weight, bias, stride, pad, relu, False)
+
+
+def conv_transpose2d(x, weight):
+    return _Conv.apply(x, weight, None, 2, 1, False, True)
+
+
+class _BatchNorm(torch.autograd.Function):
+    """y = [relu](BatchNorm2d(x) * res_scale + res), basics.py:111-123."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale):
+        x = x.contiguous()
+        res_c = res.contiguous() if res is not None else None
+        rs = float(res_scale) if res is not None else 1.0
+        y, mean, invstd = K.bn_forward(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
+                                       training, relu, res_c, rs)
+        ctx.cfg = (training, relu, rs, res is not None)
+        ctx.save_for_backward(x, y if relu else None, gamma.detach(), mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, relu, rs, has_res = ctx.cfg
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        dx, dres, dgamma, dbeta = K.bn_backward(dy.contiguous(), y, x, gamma, mean, invstd, training, relu, rs,
+                                                want_dres=has_res and ctx.needs_input_grad[9])
+        if has_res and ctx.needs_input_grad[9] and dres is None:
+            dres = dy
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu=False, res=None, res_scale=1.0):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale)
+
+
+def _gate_mlp(avg, mx, w1, w2):
+    f = torch.nn.functional
+    h = lambda v: f.linear(f.relu(f.linear(v, w1.flatten(1))), w2.flatten(1))
+    return torch.sigmoid(h(avg) + h(mx))
+
+
+class _ChannelGate(torch.autograd.Function):
+    """x * sigmoid(MLP(avgpool x) + MLP(maxpool x)); resnet_cbam.py:49-53 + basics.py:57-58.
+    Pooling / scaling / their backward are HIP kernels over the NHWC tensor; the C -> C/16 -> C MLP
+    acts on (B, C) vectors and is evaluated (and differentiated) by the host library."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2):
+        x = x.contiguous()
+        avg, mx, amax = K.gate_pool(x)
+        s = _gate_mlp(avg, mx, w1.detach().float(), w2.detach().float()).contiguous()
+        y = K.gate_scale(x, s)
+        ctx.save_for_backward(x, avg, mx, amax, s, w1.detach(), w2.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, avg, mx, amax, s, w1, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        ds = K.gate_backward_reduce(dy, x)
+        with torch.enable_grad():
+            a, m = avg.detach().requires_grad_(), mx.detach().requires_grad_()
+            w1_, w2_ = w1.float().requires_grad_(), w2.float().requires_grad_()
+            s_ = _gate_mlp(a, m, w1_, w2_)
+            davg, dmax, dw1, dw2 = torch.autograd.grad(s_, (a, m, w1_, w2_), ds)
+        dx = K.gate_backward_apply(dy, s, davg.contiguous(), dmax.contiguous(), amax)
+        return dx, dw1, dw2
+
+
+def channel_gate(x, w1, w2):
+    return _ChannelGate.apply(x, w1, w2)

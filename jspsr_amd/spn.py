@@ -31,19 +31,22 @@ class Generator(nn.Module):
         self.conv_offset = ConvUnit(bc * 4, 2 * self.num, 1, bn=False, relu=False)
 
     def features(self, dem, context):
+        """dem, context: NHWC activations (engine.from_nchw)."""
         d = self.convd2(self.convd1(dem))
         f = self.convf2(self.convf1(context))
         return self.block(self.conv(E.cat((d, f))))
 
     def heads(self, feature):
-        """weight (B,9,H,W) after the sigmoid and the 16 learned offset channels."""
+        """NHWC weight (B,H,W,9) after the sigmoid and the 16 learned offset channels (B,H,W,16)."""
         cw, co = self.conv_weight[0], self.conv_offset.conv[0]
         weight = E.sigmoid(E.conv2d(feature, cw.weight, cw.bias))
         off16 = E.conv2d(feature, co.weight, co.bias)
         return weight, off16
 
     def forward(self, dem, context):
-        weight, off16 = self.heads(self.features(dem, context))
+        """Reference contract: NCHW in, (weight (B,9,H,W), offset (B,18,H,W)) NCHW fp32 out."""
+        weight, off16 = self.heads(self.features(E.from_nchw(dem), E.from_nchw(context)))
+        weight, off16 = E.to_nchw_f32(weight), E.to_nchw_f32(off16)
         B, _, H, W = off16.shape
         zero = torch.zeros(B, 2, H, W, dtype=off16.dtype, device=off16.device)
         i = 2 * self.idx_ref
