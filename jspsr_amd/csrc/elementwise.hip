@@ -72,7 +72,25 @@ struct RedGeom {
   int C;                 // channels
   int chunks;            // pixel chunks per segment
   long long chunk_pix;   // pixels per chunk
+  int lpp;               // lanes (16-byte channel groups) per pixel inside a 64-lane row: min(64, C/N)
+  int pl;                // pixels handled side by side by one 64-lane row: 64 / lpp
 };
+
+// lane -> (channel group, pixel sub-lane).  Narrow tensors (C/N < 64) put several pixels in one
+// 64-lane row so every lane works and a wave instruction still covers contiguous memory.
+struct LaneMap {
+  int c;      // first channel of this lane's group (>= C: idle lane)
+  int sub;    // pixel sub-lane inside the row
+};
+template <int N>
+__device__ __forceinline__ LaneMap lane_map(const RedGeom& g) {
+  LaneMap m;
+  const int tx = threadIdx.x;
+  m.sub = tx / g.lpp;
+  const int cg = blockIdx.y * TX + (tx - m.sub * g.lpp);
+  m.c = (m.sub < g.pl) ? cg * N : g.C;
+  return m;
+}
 
 // Generic per-channel reduction: F supplies K accumulators per channel.
 // partial layout: [seg][chunk][K][C]
@@ -81,8 +99,8 @@ __device__ __forceinline__ void reduce_pixels(const RedGeom& g, float* __restric
   constexpr int N = V<T>::N;
   __shared__ float red[TY][K][TX * N];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int cg = blockIdx.y * TX + tx;   // channel group
-  const int c = cg * N;
+  const LaneMap lm = lane_map<N>(g);
+  const int c = lm.c;
   const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
   float acc[K][N];
 #pragma unroll
@@ -92,21 +110,22 @@ __device__ __forceinline__ void reduce_pixels(const RedGeom& g, float* __restric
   const long long p0 = chunk * g.chunk_pix;
   const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
   if (c < g.C)
-    for (long long p = p0 + ty; p < p1; p += TY) body((long long)seg * g.npix + p, c, acc);
+    for (long long p = p0 + ty * g.pl + lm.sub; p < p1; p += TY * g.pl) body((long long)seg * g.npix + p, c, acc);
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
     for (int i = 0; i < N; ++i) red[ty][k][tx * N + i] = acc[k][i];
   __syncthreads();
-  if (ty == 0 && c < g.C) {
+  if (ty == 0 && lm.sub == 0 && c < g.C) {
     float* dst = partial + ((size_t)blockIdx.x * K) * g.C + c;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         float s = 0.f;
+        for (int j = 0; j < g.pl; ++j)
 #pragma unroll
-        for (int y = 0; y < TY; ++y) s += red[y][k][tx * N + i];
+          for (int y = 0; y < TY; ++y) s += red[y][k][(tx + j * g.lpp) * N + i];
         dst[(size_t)k * g.C + i] = s;
       }
   }
@@ -123,9 +142,45 @@ RedGeom make_red(long long npix, int nseg, int C, int vec) {
   if (chunks < 1) chunks = 1;
   g.chunk_pix = (npix + chunks - 1) / chunks;
   g.chunks = (int)((npix + g.chunk_pix - 1) / g.chunk_pix);
+  const int groups = C / vec;
+  g.lpp = groups < TX ? groups : TX;
+  g.pl = TX / g.lpp;
   return g;
 }
 dim3 red_grid(const RedGeom& g, int vec) { return dim3(g.nseg * g.chunks, (g.C / vec + TX - 1) / TX); }
+
+// Same geometry without a reduction: a lane owns one 16-byte channel group (per-channel
+// parameters are loaded into registers once) and walks the pixels of its chunk.
+template <typename T, typename F>
+__device__ __forceinline__ void for_pixels(const RedGeom& g, F&& body) {
+  constexpr int N = V<T>::N;
+  const LaneMap lm = lane_map<N>(g);
+  const int c = lm.c;
+  if (c >= g.C) return;
+  const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
+  const long long p0 = chunk * g.chunk_pix;
+  const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
+  for (long long p = p0 + threadIdx.y * g.pl + lm.sub; p < p1; p += TY * g.pl) body(seg, p, (long long)seg * g.npix + p, c);
+}
+
+template <int N>
+__device__ __forceinline__ void load_param(const float* __restrict__ p, float (&f)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; i += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + i);
+    f[i] = v.x; f[i + 1] = v.y; f[i + 2] = v.z; f[i + 3] = v.w;
+  }
+}
+
+// One wave sums column `off` of the partial rows (row pitch `pitch` floats) in fp64, fixed order.
+__device__ __forceinline__ double wave_sum_rows(const float* __restrict__ partial, int rows, size_t pitch, size_t off) {
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int r = lane; r < rows; r += 64) s += (double)partial[(size_t)r * pitch + off];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  return s;
+}
 
 // ---------------------------------------------------------------- BatchNorm forward
 template <typename T>
@@ -147,15 +202,16 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, 
                                    float momentum, float eps, int training, float* __restrict__ save_mean,
                                    float* __restrict__ save_invstd, float* __restrict__ scale,
                                    float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel
   if (c >= C) return;
   float mean, var;
+  double s = 0.0, ss = 0.0;
   if (training) {
-    double s = 0.0, ss = 0.0;
-    for (int r = 0; r < rows; ++r) {
-      s += (double)partial[((size_t)r * 2) * C + c];
-      ss += (double)partial[((size_t)r * 2 + 1) * C + c];
-    }
+    s = wave_sum_rows(partial, rows, (size_t)2 * C, c);
+    ss = wave_sum_rows(partial, rows, (size_t)2 * C, (size_t)C + c);
+  }
+  if ((threadIdx.x & 63) != 0) return;
+  if (training) {
     const double m = s / (double)count;
     double v = ss / (double)count - m * m;
     if (v < 0.0) v = 0.0;
@@ -180,29 +236,28 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, 
 
 // y = [relu]( (x*scale + shift) * res_scale + res )
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int x_cs, int x_coff,
-                                                      const T* __restrict__ res, int r_cs, int r_coff,
-                                                      T* __restrict__ y, int y_cs, int y_coff,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      float res_scale, int relu, long long npix, int C) {
+__global__ __launch_bounds__(TX * TY) void bn_apply_kernel(const T* __restrict__ x, int x_cs, int x_coff,
+                                                          const T* __restrict__ res, int r_cs, int r_coff,
+                                                          T* __restrict__ y, int y_cs, int y_coff,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float res_scale, int relu, RedGeom g) {
   constexpr int N = V<T>::N;
-  const int groups = C / N;
-  const long long total = npix * groups;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / groups;
-    const int c = (int)(i % groups) * N;
+  float sc[N], sh[N];
+  const int c0 = lane_map<N>(g).c;
+  if (c0 < g.C) { load_param<N>(scale + c0, sc); load_param<N>(shift + c0, sh); }
+  for_pixels<T>(g, [&](int, long long, long long pix, int c) {
     float f[N], r[N];
     load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, f);
     if (res) load_vec<T>(res + (size_t)pix * r_cs + r_coff + c, r);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      float v = f[k] * scale[c + k] + shift[c + k];
+      float v = f[k] * sc[k] + sh[k];
       if (res) v = v * res_scale + r[k];
       if (relu) v = fmaxf(v, 0.f);
       f[k] = v;
     }
     store_vec<T>(y + (size_t)pix * y_cs + y_coff + c, f);
-  }
+  });
 }
 
 // ---------------------------------------------------------------- BatchNorm backward
@@ -234,13 +289,11 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        int training, float res_scale, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel
   if (c >= C) return;
-  double s = 0.0, sx = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s += (double)partial[((size_t)r * 2) * C + c];
-    sx += (double)partial[((size_t)r * 2 + 1) * C + c];
-  }
+  const double s = wave_sum_rows(partial, rows, (size_t)2 * C, c);
+  const double sx = wave_sum_rows(partial, rows, (size_t)2 * C, (size_t)C + c);
+  if ((threadIdx.x & 63) != 0) return;
   // the BN branch sees dz * res_scale
   dbeta[c] = (float)(s * res_scale);
   dgamma[c] = (float)(sx * res_scale);
@@ -251,18 +304,21 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
-                                                          const T* __restrict__ y, int y_cs, int y_coff,
-                                                          const T* __restrict__ x, int x_cs, int x_coff,
-                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          const float* __restrict__ coef, int relu,
-                                                          T* __restrict__ dx, T* __restrict__ dres, long long npix, int C) {
+__global__ __launch_bounds__(TX * TY) void bn_bwd_apply_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
+                                                              const T* __restrict__ y, int y_cs, int y_coff,
+                                                              const T* __restrict__ x, int x_cs, int x_coff,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ coef, int relu,
+                                                              T* __restrict__ dx, T* __restrict__ dres, RedGeom g) {
   constexpr int N = V<T>::N;
-  const int groups = C / N;
-  const long long total = npix * groups;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / groups;
-    const int c = (int)(i % groups) * N;
+  const int C = g.C;
+  float mu[N], is[N], k0[N], ka[N], kb[N];
+  const int c0 = lane_map<N>(g).c;
+  if (c0 < C) {
+    load_param<N>(mean + c0, mu); load_param<N>(invstd + c0, is);
+    load_param<N>(coef + c0, k0); load_param<N>(coef + C + c0, ka); load_param<N>(coef + 2 * C + c0, kb);
+  }
+  for_pixels<T>(g, [&](int, long long, long long pix, int c) {
     float d[N], xv[N], yv[N], o[N];
     load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
     load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, xv);
@@ -271,12 +327,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (int k = 0; k < N; ++k) {
       const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : d[k];
       d[k] = dz;
-      const float xhat = (xv[k] - mean[c + k]) * invstd[c + k];
-      o[k] = coef[c + k] * (dz - coef[C + c + k] - xhat * coef[2 * C + c + k]);
+      const float xhat = (xv[k] - mu[k]) * is[k];
+      o[k] = k0[k] * (dz - ka[k] - xhat * kb[k]);
     }
     store_vec<T>(dx + (size_t)pix * C + c, o);
     if (dres) store_vec<T>(dres + (size_t)pix * C + c, d);
-  }
+  });
 }
 
 // ---------------------------------------------------------------- ReLU backward + bias gradient
@@ -299,11 +355,10 @@ __global__ __launch_bounds__(TX * TY) void act_bwd_kernel(const T* __restrict__ 
 }
 
 __global__ void sum_rows_kernel(const float* __restrict__ partial, int rows, int K, int k, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel
   if (c >= C) return;
-  double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)partial[((size_t)r * K + k) * C + c];
-  out[c] = (float)s;
+  const double s = wave_sum_rows(partial, rows, (size_t)K * C, (size_t)k * C + c);
+  if ((threadIdx.x & 63) == 0) out[c] = (float)s;
 }
 
 // ---------------------------------------------------------------- ChannelAttention pieces
@@ -316,7 +371,8 @@ __global__ __launch_bounds__(TX * TY) void gate_pool_kernel(const T* __restrict_
   __shared__ float rs[TY][TX * N], rm[TY][TX * N];
   __shared__ int ri[TY][TX * N];
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int c = (blockIdx.y * TX + tx) * N;
+  const LaneMap lm = lane_map<N>(g);
+  const int c = lm.c;
   const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
   float s[N], m[N];
   int idx[N];
@@ -325,7 +381,7 @@ __global__ __launch_bounds__(TX * TY) void gate_pool_kernel(const T* __restrict_
   const long long p0 = chunk * g.chunk_pix;
   const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
   if (c < g.C)
-    for (long long p = p0 + ty; p < p1; p += TY) {
+    for (long long p = p0 + ty * g.pl + lm.sub; p < p1; p += TY * g.pl) {
       float f[N];
       load_vec<T>(x + ((size_t)seg * g.npix + p) * g.C + c, f);
 #pragma unroll
@@ -337,16 +393,18 @@ __global__ __launch_bounds__(TX * TY) void gate_pool_kernel(const T* __restrict_
 #pragma unroll
   for (int i = 0; i < N; ++i) { rs[ty][tx * N + i] = s[i]; rm[ty][tx * N + i] = m[i]; ri[ty][tx * N + i] = idx[i]; }
   __syncthreads();
-  if (ty == 0 && c < g.C) {
+  if (ty == 0 && lm.sub == 0 && c < g.C) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       float ss = 0.f, mm = -INFINITY;
       int ii = 0x7fffffff;
+      for (int q = 0; q < g.pl; ++q)
 #pragma unroll
       for (int y = 0; y < TY; ++y) {
-        ss += rs[y][tx * N + i];
-        const float v = rm[y][tx * N + i];
-        const int j = ri[y][tx * N + i];
+        const int col = (tx + q * g.lpp) * N + i;
+        ss += rs[y][col];
+        const float v = rm[y][col];
+        const int j = ri[y][col];
         if (v > mm || (v == mm && j < ii)) { mm = v; ii = j; }
       }
       const size_t o = (size_t)blockIdx.x * g.C + c + i;
@@ -375,21 +433,19 @@ __global__ void gate_pool_finalize_kernel(const float* __restrict__ psum, const 
 
 // y[b,p,c] = x[b,p,c] * s[b,c]
 template <typename T>
-__global__ __launch_bounds__(256) void gate_scale_kernel(const T* __restrict__ x, const float* __restrict__ s,
-                                                        T* __restrict__ y, long long npix, int C, int B) {
+__global__ __launch_bounds__(TX * TY) void gate_scale_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                            T* __restrict__ y, RedGeom g) {
   constexpr int N = V<T>::N;
-  const int groups = C / N;
-  const long long total = (long long)B * npix * groups;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / groups;
-    const int c = (int)(i % groups) * N;
-    const int b = (int)(pix / npix);
+  float sv[N];
+  const int c0 = lane_map<N>(g).c;
+  if (c0 < g.C) load_param<N>(s + (size_t)(blockIdx.x / g.chunks) * g.C + c0, sv);
+  for_pixels<T>(g, [&](int, long long, long long pix, int c) {
     float f[N];
-    load_vec<T>(x + (size_t)pix * C + c, f);
+    load_vec<T>(x + (size_t)pix * g.C + c, f);
 #pragma unroll
-    for (int k = 0; k < N; ++k) f[k] *= s[(size_t)b * C + c + k];
-    store_vec<T>(y + (size_t)pix * C + c, f);
-  }
+    for (int k = 0; k < N; ++k) f[k] *= sv[k];
+    store_vec<T>(y + (size_t)pix * g.C + c, f);
+  });
 }
 
 // ds[b,c] = sum_p dy*x
@@ -416,28 +472,27 @@ __global__ void gate_bwd_finalize_kernel(const float* __restrict__ partial, int 
 
 // dx = dy*s + davg/npix + [p == argmax] dmax
 template <typename T>
-__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ s,
-                                                            const float* __restrict__ davg, const float* __restrict__ dmax,
-                                                            const int* __restrict__ amax, T* __restrict__ dx,
-                                                            long long npix, int C, int B) {
+__global__ __launch_bounds__(TX * TY) void gate_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ s,
+                                                                const float* __restrict__ davg, const float* __restrict__ dmax,
+                                                                const int* __restrict__ amax, T* __restrict__ dx, RedGeom g) {
   constexpr int N = V<T>::N;
-  const int groups = C / N;
-  const long long total = (long long)B * npix * groups;
-  const float inv = 1.f / (float)npix;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long pix = i / groups;
-    const int c = (int)(i % groups) * N;
-    const int b = (int)(pix / npix);
-    const int p = (int)(pix - (long long)b * npix);
-    float f[N];
-    load_vec<T>(dy + (size_t)pix * C + c, f);
+  float sv[N], da[N], dm[N];
+  int am[N];
+  const int c0 = lane_map<N>(g).c;
+  const float inv = 1.f / (float)g.npix;
+  if (c0 < g.C) {
+    const size_t o = (size_t)(blockIdx.x / g.chunks) * g.C + c0;
+    load_param<N>(s + o, sv); load_param<N>(davg + o, da); load_param<N>(dmax + o, dm);
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const size_t o = (size_t)b * C + c + k;
-      f[k] = f[k] * s[o] + davg[o] * inv + (amax[o] == p ? dmax[o] : 0.f);
-    }
-    store_vec<T>(dx + (size_t)pix * C + c, f);
+    for (int k = 0; k < N; ++k) { am[k] = amax[o + k]; da[k] *= inv; }
   }
+  for_pixels<T>(g, [&](int, long long p, long long pix, int c) {
+    float f[N];
+    load_vec<T>(dy + (size_t)pix * g.C + c, f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) f[k] = f[k] * sv[k] + da[k] + (am[k] == (int)p ? dm[k] : 0.f);
+    store_vec<T>(dx + (size_t)pix * g.C + c, f);
+  });
 }
 
 int ew_blocks(long long total) {
@@ -492,12 +547,13 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
                                        static_cast<const T*>(x), x_cs, x_coff, g, partial));
     if (int e = check_launch("bn_stats")) return e;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, rows, C, npix, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, rows, C, npix, gamma, beta,
                      running_mean, running_var, momentum, eps, training, save_mean, save_invstd, scale, shift);
   if (int e = check_launch("bn_finalize")) return e;
-  DISPATCH(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_blocks(npix * (C / vec))), dim3(256), 0, s,
+  const RedGeom ga = make_red(npix, 1, C, vec);
+  DISPATCH(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, red_grid(ga, vec), dim3(TX, TY), 0, s,
                                      static_cast<const T*>(x), x_cs, x_coff, static_cast<const T*>(res), r_cs, r_coff,
-                                     static_cast<T*>(y), y_cs, y_coff, scale, shift, res_scale, relu, npix, C));
+                                     static_cast<T*>(y), y_cs, y_coff, scale, shift, res_scale, relu, ga));
   return check_launch("bn_apply");
 }
 
@@ -521,13 +577,13 @@ extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_co
                                      static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
                                      static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, relu, g, partial));
   if (int e = check_launch("bn_bwd_reduce")) return e;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, g.chunks, C, npix, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, C, npix, gamma,
                      save_invstd, training, res_scale, dgamma, dbeta, coef);
   if (int e = check_launch("bn_bwd_finalize")) return e;
-  DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_blocks(npix * (C / vec))), dim3(256), 0, s,
+  DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
                                      static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
                                      static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, coef, relu,
-                                     static_cast<T*>(dx), static_cast<T*>(dres), npix, C));
+                                     static_cast<T*>(dx), static_cast<T*>(dres), g));
   return check_launch("bn_bwd_apply");
 }
 
@@ -544,7 +600,7 @@ extern "C" int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_c
                                      dy_cs, dy_coff, static_cast<const T*>(y), relu, static_cast<T*>(dz), dz_cs, g, partial));
   if (int e = check_launch("act_backward")) return e;
   if (dbias) {
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, g.chunks, 1, 0, C, dbias);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, 1, 0, C, dbias);
     return check_launch("act_backward_bias");
   }
   return JSPSR_OK;
@@ -576,8 +632,9 @@ extern "C" int jspsr_gate_scale(int dtype, const void* x, const float* s_, void*
   if (!x || !s_ || !y || B <= 0 || npix <= 0) return fail(JSPSR_EINVAL, "gate_scale: bad arguments");
   const int vec = dtype == JSPSR_F32 ? 4 : 8;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DISPATCH(dtype, hipLaunchKernelGGL(gate_scale_kernel<T>, dim3(ew_blocks((long long)B * npix * (C / vec))), dim3(256), 0, s,
-                                     static_cast<const T*>(x), s_, static_cast<T*>(y), npix, C, B));
+  const RedGeom g = make_red(npix, B, C, vec);
+  DISPATCH(dtype, hipLaunchKernelGGL(gate_scale_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
+                                     static_cast<const T*>(x), s_, static_cast<T*>(y), g));
   return check_launch("gate_scale");
 }
 
@@ -603,7 +660,8 @@ extern "C" int jspsr_gate_backward_apply(int dtype, const void* dy, const float*
     return fail(JSPSR_EINVAL, "gate_backward_apply: bad arguments");
   const int vec = dtype == JSPSR_F32 ? 4 : 8;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DISPATCH(dtype, hipLaunchKernelGGL(gate_bwd_apply_kernel<T>, dim3(ew_blocks((long long)B * npix * (C / vec))), dim3(256), 0,
-                                     s, static_cast<const T*>(dy), s_, davg, dmax, amax, static_cast<T*>(dx), npix, C, B));
+  const RedGeom g = make_red(npix, B, C, vec);
+  DISPATCH(dtype, hipLaunchKernelGGL(gate_bwd_apply_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
+                                     static_cast<const T*>(dy), s_, davg, dmax, amax, static_cast<T*>(dx), g));
   return check_launch("gate_backward_apply");
 }

@@ -129,11 +129,10 @@ class _Conv(torch.autograd.Function):
             dz, dbias = K.act_backward(dy, y, relu, want_dz=relu, want_dbias=has_bias)
             if dz is None:
                 dz = dy
-        else:  # tiny heads (9 channels): host-side glue on (B,H,W,9)
-            dz = dy * (y > 0) if relu else dy
+        else:  # tiny heads (9 channels): pad the channel pitch to a chunk, then the same kernel
+            dz = pad_channels(dy * (y > 0) if relu else dy, e).contiguous()
             if has_bias:
-                dbias = dz.float().sum((0, 1, 2))
-            dz = pad_channels(dz, e).contiguous()
+                dbias = K.act_backward(dz, None, False, want_dz=False, want_dbias=True)[1][:Co]
         B, H, W, Cp = x.shape
         dx = dW = None
         if not transposed:
