@@ -56,54 +56,67 @@ def synthetic_batch(B, H, W, device, seed):
 
 
 def time_k1(model, inputs, iters=20):
-    """Roofline of K1 on this batch's real affinities/offsets (events on the launch stream)."""
+    """Roofline of K1 (the HBM-bound propagation kernels) at this batch's shape.
+
+    Each kernel is launched `iters` times back to back through the C ABI between two events
+    recorded on the launch stream (torch's current stream is the stream handed to the ABI), so the
+    figure is the average launch duration incl. the ~1-2 us inter-launch gap.  Operand sets rotate
+    over > 256 MiB so the Infinity Cache cannot serve them.
+    """
     from jspsr_amd import ops
     dem = inputs[0]
     B, _, H, W = dem.shape
-    g = torch.Generator(device=dem.device).manual_seed(1)
-    # several operand sets: defeat the 256 MiB Infinity Cache so HBM is what is measured
-    nset = 4
-    sets = []
-    for _ in range(nset):
-        wgt = torch.sigmoid(torch.randn(B, 9, H, W, device=dem.device, generator=g))
-        off = 1.5 * torch.randn(B, 16, H, W, device=dem.device, generator=g)
-        sets.append((wgt.requires_grad_(), off.requires_grad_()))
-    w = model.postprocessor.w.detach().clone().requires_grad_()
-    b = model.postprocessor.b.detach().clone().requires_grad_()
-    gout = torch.randn(B, 1, H, W, device=dem.device, generator=g)
+    dev = dem.device
+    g = torch.Generator(device=dev).manual_seed(1)
+    nset = max(2, int(700e6 // (B * H * W * 4 * 26)) + 1)
+    sets = [(torch.sigmoid(torch.randn(B, 9, H, W, device=dev, generator=g)),
+             1.5 * torch.randn(B, 16, H, W, device=dev, generator=g)) for _ in range(nset)]
+    gsets = [(torch.empty(B, 9, H, W, device=dev), torch.empty(B, 16, H, W, device=dev)) for _ in range(nset)]
+    w = model.postprocessor.w.detach().clone()
+    b = model.postprocessor.b.detach().clone()
+    gout = torch.randn(B, 1, H, W, device=dev, generator=g)
+    out = torch.empty_like(dem)
+    gw, gb = torch.empty_like(w), torch.empty_like(b)
+    ws = ops.prop_backward_workspace(B, H, W, dev)
+
+    def fwd(i):
+        ops.prop_forward_raw(dem, sets[i % nset][0], sets[i % nset][1], w, b, 1.0, out)
+
+    def bwd(i):
+        ops.prop_backward_raw(gout, dem, sets[i % nset][0], sets[i % nset][1], w, gsets[i % nset][0],
+                              gsets[i % nset][1], gw, gb, ws)
+
     res = {}
-    outs = [ops.propagate(dem, wt, of, w, b) for wt, of in sets]
-    for name in ("fwd", "bwd"):
+    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+        for i in range(3):
+            fn(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tot = 0.0
-        for it in range(iters + 3):
-            wt, of = sets[it % nset]
-            if name == "fwd":
-                with torch.no_grad():
-                    e0.record()
-                    ops.propagate(dem, wt, of, w, b)
-                    e1.record()
-            else:
-                o = outs[it % nset]
-                e0.record()
-                torch.autograd.grad(o, (wt, of, w, b), gout, retain_graph=True)
-                e1.record()
-            e1.synchronize()
-            if it >= 3:
-                tot += e0.elapsed_time(e1)
-        res[name] = tot / iters * 1e-3
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        e1.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e-3
     px = B * H * W
-    # 16-channel offset layout (centre pair dropped): 108 B/px forward, 208 B/px backward
+    # 16-channel offset layout (the all-zero centre pair is not stored): 108 B/px fwd, 208 B/px bwd
     fb, bb = 108.0 * px, 208.0 * px
     bw_f, bw_b = fb / res["fwd"] / 1e9, bb / res["bwd"] / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "k1_pmc.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc))
     return {
-        "bound": "hbm", "kernel": "prop_bwd_kernel<16>", "achieved": round(bw_b, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(bw_b / HBM_PEAK_GBS, 4), "traffic": None,
+        "bound": "hbm", "kernel": "prop_bwd_kernel<16> (+ 10-block finalize)", "achieved": round(bw_b, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bw_b / HBM_PEAK_GBS, 4),
+        "traffic": traffic.get("bwd_bytes_per_launch") if traffic else None,
         "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2),
         "forward": {"kernel": "prop_fwd_kernel<16>", "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get("fwd_bytes_per_launch") if traffic else None,
                     "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2)},
-        "note": "algorithmic bytes (SURVEY 8d, 16-ch offsets: 108/208 B per pixel) / event-timed launch "
-                "(includes host launch gap); rocprofv3 kernel-trace figure in profiles/",
+        "note": "algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / "
+                "mean launch duration (events on the launch stream, back-to-back launches); traffic = PMC "
+                "FETCH_SIZE+WRITE_SIZE per launch from profiles/k1_pmc.json (separate rocprofv3 --pmc passes)",
     }
 
 

@@ -30,6 +30,7 @@ constexpr int NRED = 10;  // grad_wk[9] + grad_b0
 
 struct Geom {
   int B, H, W, tiles_x, tiles_y, nblk, th;
+  int dem_vec4;  // DEM rows may be staged with 16-byte loads (W % 4 == 0 and a 16-byte aligned base)
 };
 
 // PX consecutive pixels of one plane per lane: PX*4-byte loads when the row pitch and the
@@ -73,9 +74,9 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const Vec<PX>& r, int
 }
 
 // Stage the DEM tile + halo of image `img` into LDS; zero outside the raster.
-template <bool VEC, int LH>
+template <int LH>
 __device__ __forceinline__ void stage_dem(float* __restrict__ lds, const float* __restrict__ img,
-                                          int ty0, int tx0, int H, int W) {
+                                          int ty0, int tx0, int H, int W, const bool VEC) {
   for (int i = threadIdx.x; i < LH * (LW / 4); i += NT) {
     const int r = i / (LW / 4), c = (i % (LW / 4)) * 4;
     const int gy = ty0 - HALO + r, gx = tx0 - HALO + c;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
   const int H = g.H, W = g.W;
   const size_t P = (size_t)H * W;
   const float* img = dem + (size_t)b * P;
-  stage_dem<VEC, LH>(lds, img, ty0, tx0, H, W);
+  stage_dem<LH>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
   const int H = g.H, W = g.W;
   const size_t P = (size_t)H * W;
   const float* img = dem + (size_t)b * P;
-  stage_dem<VEC, LH>(lds, img, ty0, tx0, H, W);
+  stage_dem<LH>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
@@ -331,27 +332,31 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
   }
 }
 
-// One workgroup of NRED waves: wave i sums column i of partial[nblk][NRED] (fixed order:
-// bit-reproducible run to run).
-__global__ __launch_bounds__(64 * NRED) void prop_bwd_finalize(const float* __restrict__ partial,
-                                                              int nblk, float* __restrict__ gwk,
-                                                              float* __restrict__ gb0) {
-  const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// One workgroup per parameter gradient (9 tap weights + bias): 256 lanes stride over the partial
+// rows in fp64, then a fixed-order tree -> bit-reproducible run to run.
+__global__ __launch_bounds__(256) void prop_bwd_finalize(const float* __restrict__ partial,
+                                                        int nblk, float* __restrict__ gwk,
+                                                        float* __restrict__ gb0) {
+  __shared__ double red[4];
+  const int col = blockIdx.x;
   double s = 0.0;
-  for (int i = lane; i < nblk; i += 64) s += (double)partial[(size_t)i * NRED + col];
+  for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partial[(size_t)i * NRED + col];
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
-  if (lane == 0) {
-    if (col < 9) gwk[col] = (float)s; else gb0[0] = (float)s;
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (col < 9) gwk[col] = (float)t; else gb0[0] = (float)t;
   }
 }
 
-// Tile height.  Tunable through JSPSR_PROP_TH (4, 8 or 16).
+// Tile height.  Tunable through JSPSR_PROP_TH (4, 8 or 16); 8 measured best on MI355X.
 int prop_th() {
   static const int th = [] {
     const char* e = getenv("JSPSR_PROP_TH");
-    const int v = e ? atoi(e) : 16;
-    return (v == 4 || v == 8 || v == 16) ? v : 16;
+    const int v = e ? atoi(e) : 8;
+    return (v == 4 || v == 8 || v == 16) ? v : 8;
   }();
   return th;
 }
@@ -404,6 +409,7 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
     if (!jspsr::aligned4(p)) return jspsr::fail(JSPSR_EALIGN, "prop_forward: pointer not 4-byte aligned");
   const int px = prop_px();
   const bool vec = can_vec(W, px, {dem, weight, offset, out});
+  g.dem_vec4 = can_vec(W, 4, {dem});
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(g.nblk), block(NT);
 #define LAUNCH_TH(OC, PX, V, T) hipLaunchKernelGGL((prop_fwd_kernel<OC, PX, V, T>), grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g)
@@ -439,6 +445,7 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
   if (!jspsr::aligned16(workspace)) return jspsr::fail(JSPSR_EALIGN, "prop_backward: workspace not 16-byte aligned");
   const int px = prop_px();
   const bool vec = can_vec(W, px, {grad_out, dem, weight, offset, grad_weight, grad_offset});
+  g.dem_vec4 = can_vec(W, 4, {dem});
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   dim3 grid(g.nblk), block(NT);
@@ -450,6 +457,6 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
 #undef BY_VEC
 #undef BY_PX
   if (int e = jspsr::check_launch("prop_backward")) return e;
-  hipLaunchKernelGGL(prop_bwd_finalize, dim3(1), dim3(64 * NRED), 0, s, partial, g.nblk, grad_wk, grad_b0);
+  hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, g.nblk, grad_wk, grad_b0);
   return jspsr::check_launch("prop_backward_finalize");
 }

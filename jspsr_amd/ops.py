@@ -22,6 +22,29 @@ def _need_gpu(*ts):
             raise TypeError(f"expected float32, got {t.dtype}")
 
 
+def prop_forward_raw(dem, weight, offset, w, b, scale, out):
+    """Launch K1 forward on raw, contiguous fp32 operands (no autograd bookkeeping)."""
+    B, _, H, W = dem.shape
+    lib = _lib.load()
+    _lib.check(lib.jspsr_prop_forward_f32(dem.data_ptr(), weight.data_ptr(), offset.data_ptr(), offset.shape[1],
+                                          w.data_ptr(), b.data_ptr(), float(scale), out.data_ptr(), B, H, W, _stream()),
+               "jspsr_prop_forward_f32")
+
+
+def prop_backward_raw(grad_out, dem, weight, offset, w, gweight, goffset, gw, gb, ws):
+    B, _, H, W = dem.shape
+    lib = _lib.load()
+    _lib.check(lib.jspsr_prop_backward_f32(grad_out.data_ptr(), dem.data_ptr(), weight.data_ptr(), offset.data_ptr(),
+                                           offset.shape[1], w.data_ptr(), gweight.data_ptr(), goffset.data_ptr(),
+                                           gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), B, H, W, _stream()),
+               "jspsr_prop_backward_f32")
+
+
+def prop_backward_workspace(B, H, W, device):
+    n = _lib.load().jspsr_prop_backward_workspace_bytes(B, H, W)
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device)
+
+
 class _Propagate(torch.autograd.Function):
     """PostProcessor.forward (models/components/spn.py:99-118) as one HIP kernel each way."""
 

@@ -60,7 +60,10 @@ def test_golden_fixture(golden_dir, oc):
     t = lambda k: torch.from_numpy(z[k]).float()
     got = _run_hip(t("dem"), t("weight"), t("offset"), t("w"), t("b"), t("grad_out"), oc)
     # compare with the oracle evaluated on the same fp32-rounded inputs (fp64 arithmetic)
-    exp = _run_oracle64(t("dem"), t("weight"), t("offset"), t("w"), t("b"), t("grad_out"))
+    exp = list(_run_oracle64(t("dem"), t("weight"), t("offset"), t("w"), t("b"), t("grad_out")))
+    if oc == 16:  # the 16-channel layout has no centre-tap offset, hence no gradient for it
+        exp[2] = exp[2].clone()
+        exp[2][:, 8:10] = 0
     off = t("offset").double().reshape(2, 9, 2, 20, 24)
     near = (off.abs().amax((1, 2)) < 20).unsqueeze(1)  # |p| ~ 100 px: fp32 coordinate rounding, see below
     _close(got[0] * near, exp[0] * near, 1e-5, 2e-6, "out")
@@ -84,12 +87,29 @@ def test_golden_fixture(golden_dir, oc):
 def test_random_cases(shape, sigma, oc):
     case = _rand_case(*shape, sigma, seed=sum(shape) + int(sigma * 10))
     got = _run_hip(*case, oc=oc)
-    exp = _run_oracle64(*case)
-    _close(got[0], exp[0], 1e-5, 2e-6, "out")
-    _close(got[1], exp[1], 1e-5, 5e-6, "grad_weight")
-    _close(got[2], exp[2], 1e-4, 5e-6, "grad_offset")
-    _close(got[3], exp[3], 1e-4, 2e-4, "grad_w")
-    _close(got[4], exp[4], 1e-5, 2e-4, "grad_b")
+    exp = list(_run_oracle64(*case))
+    if oc == 16:
+        exp[2] = exp[2].clone()
+        exp[2][:, 8:10] = 0
+    # fp32 coordinates: ulp(p) ~ 4e-6 at |p| ~ 50 px times the white-noise DEM's unit slope
+    tol = 2e-5 if sigma <= 3 else 1e-4
+    _close(got[0], exp[0], 1e-5, tol, "out")
+    _close(got[1], exp[1], 1e-5, tol, "grad_weight")
+    # d/d(offset) of a bilinear sample jumps at integer coordinates: skip samples whose fp32
+    # coordinate could land on the other side of the kink (|frac| < 1e-4)
+    off = case[2].double()
+    B, _, H, W = off.shape
+    ys = torch.arange(H, dtype=torch.float64).view(1, 1, H, 1)
+    xs = torch.arange(W, dtype=torch.float64).view(1, 1, 1, W)
+    pos = off.clone()
+    pos[:, 0::2] += ys
+    pos[:, 1::2] += xs
+    frac = (pos - pos.round()).abs().reshape(B, 9, 2, H, W)
+    smooth = (frac.amin(2, keepdim=True) > 1e-4).expand(B, 9, 2, H, W).reshape(B, 18, H, W)
+    _close(got[2] * smooth, exp[2] * smooth, 1e-4, 2 * tol, "grad_offset")
+    assert sigma == 0 or smooth.double().mean() > 0.85  # the centre tap (offset 0) always sits on a kink
+    _close(got[3], exp[3], 1e-4, 5e-4, "grad_w")
+    _close(got[4], exp[4], 1e-5, 5e-4, "grad_b")
 
 
 def test_matches_c_oracle_fp32_bitclose():
@@ -170,4 +190,4 @@ def test_full_size_properties():
     off18 = torch.cat((offset[:, :8], torch.zeros_like(offset[:, :2]), offset[:, 8:]), 1)
     ref = R.propagate(dem.cpu().double(), weight.detach().cpu().double(), off18.detach().cpu().double(),
                       w.detach().cpu().double(), b.detach().cpu().double())
-    _close(o1.detach().cpu()[sl], ref[sl], 1e-5, 2e-6, "sub-block")
+    _close(o1.detach().cpu()[sl], ref[sl], 1e-5, 3e-5, "sub-block")  # fp32 coordinates at |p| ~ 500 px
