@@ -2,6 +2,8 @@
 // Design notes: conv_igemm.h.  Entry points: include/jspsr_hip.h (jspsr_conv2d_*, jspsr_pack_weight).
 #include "conv_igemm.h"
 
+#include <type_traits>
+
 namespace {
 
 using namespace jspsr;
@@ -37,7 +39,9 @@ struct RowInfo {  // one per tile row (m-pixel), staged in LDS
   int opix;       // written pixel index (b*OH + oy)*OW + ox, -1: nothing to write
 };
 
-template <typename T, int BM, int BN, int WGM, int WGN>
+// UNI: Cin is a multiple of the stage depth BK, so every 16-byte chunk of a stage belongs to the
+// same tap -> the tap walk is wave-uniform (scalar registers, scalar offset of the buffer loads).
+template <typename T, int BM, int BN, int WGM, int WGN, bool UNI>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__ in,
                                                           const T* __restrict__ wgt,
                                                           const float* __restrict__ bias,
@@ -50,15 +54,15 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
   using frag_t = typename Frag<T>::type;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int AS_BYTES = BM * ROWB, BS_BYTES = BN * ROWB;   // one buffer
   char* As = smem;                                  // [2][BM][ROWB]
-  char* Bs = smem + 2 * BM * ROWB;                  // [2][BN][ROWB]
-  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + 2 * (BM + BN) * ROWB);  // [BM]
+  char* Bs = smem + 2 * AS_BYTES;                   // [2][BN][ROWB]
+  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + 2 * (AS_BYTES + BS_BYTES));  // [BM]
 
   const int tid = threadIdx.x;
   const int M = g.B * g.MH * g.MW;
   const int ntn = (g.Cout + BN - 1) / BN;
-  const int nblk = gridDim.x;
-  const int t = xcd_contiguous(blockIdx.x, nblk);
+  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
   const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
 
   if (tid < BM) {
@@ -80,67 +84,131 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
   }
   __syncthreads();
 
-  // this thread's staging slots: chunk `ch` of rows (tid/8 + 32*i)
+  // ---- staging plan -------------------------------------------------------------------------
+  // This thread stages 16-byte chunk `ch` of tile rows r0 + 32*i.  Everything that does not change
+  // along K is folded into per-row 32-bit byte offsets relative to a workgroup-uniform base (buffer
+  // descriptors: an out-of-range offset makes the hardware return zeros without touching memory --
+  // that is the zero padding and every other mask) and per-row validity bits over the tap walk.
   const int ch = tid & (NCH - 1);
   const int r0 = tid >> 3;
-  int rb[A_IT], riy[A_IT], rix[A_IT];
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const RowInfo rfirst = rows[0];
+  const long long refpix = ((long long)(rfirst.b < 0 ? 0 : rfirst.b) * g.IH + rfirst.iy0) * g.IW + rfirst.ix0;
+  const long long reach = (long long)(g.nty > 0 ? g.nty - 1 : 0) * g.IW + (g.ntx > 0 ? g.ntx - 1 : 0);
+  const long long basepix = refpix - (g.sign < 0 ? reach : 0);   // lowest pixel any tap of row 0 touches
+  const char* abase = reinterpret_cast<const char*>(in) + (basepix * g.in_cstride + g.in_coff) * (long long)sizeof(T);
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, 0xFFFFFF00u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(wgt)), 0, 0xFFFFFF00u, 0x00020000);
+  // validity of tap (ty,tx) for a row is separable: bit ty of ymask AND bit tx of xmask
+  unsigned aoff[A_IT], ymask[A_IT], xmask[A_IT], boff[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const RowInfo ri = rows[r0 + 32 * i];
-    rb[i] = ri.b;
-    riy[i] = ri.iy0;
-    rix[i] = ri.ix0;
+    unsigned ym = 0, xm = 0;
+    long long rel = 0;
+    if (ri.b >= 0) {
+      // taps q with 0 <= i0 + sign*q < extent form one contiguous run [lo, hi] of the walk
+      auto run = [&](int i0, int extent, int n) -> unsigned {
+        int lo, hi;
+        if (g.sign > 0) { lo = -i0; hi = extent - 1 - i0; } else { lo = i0 - (extent - 1); hi = i0; }
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > n - 1 ? n - 1 : hi;
+        return hi < lo ? 0u : ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+      };
+      ym = run(ri.iy0, g.IH, g.nty);
+      xm = run(ri.ix0, g.IW, g.ntx);
+      const long long pix = ((long long)ri.b * g.IH + ri.iy0) * g.IW + ri.ix0;
+      rel = (pix - refpix) * g.in_cstride * (long long)sizeof(T);   // >= 0: rows ascend with m
+      if (rel < 0 || rel > 0xE0000000LL) ym = 0;  // cannot happen for tensors < 3.5 GiB; stay safe
+    }
+    ymask[i] = ym;
+    xmask[i] = xm;
+    aoff[i] = (unsigned)rel + (UNI ? ch * 16u : 0u);
   }
   const int Ktot_w = g.KH * g.KW * g.Cin;  // packed weight row length
-  const int K = g.nty * g.ntx * g.Cin;     // walked K
+  const int K = g.nty * g.ntx * g.Cin;     // walked K (0 for a stride phase that no tap reaches)
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int r = r0 + 32 * i, n = n0 + r;
+    boff[i] = (K > 0 && r < BN && n < g.Cout) ? (unsigned)((size_t)n * Ktot_w * sizeof(T)) + (UNI ? ch * 16u : 0u) : OOB;
+  }
   const int KT = (K + BK - 1) / BK;
+  const int pix_bytes = g.in_cstride * (int)sizeof(T);
 
-  // tap walk state of this thread's chunk
-  int ci = ch * EPC, ty = 0, tx = 0;
+  // tap walk state: of the whole stage (UNI, scalar) or of this thread's chunk
+  int ci = UNI ? 0 : ch * EPC, ty = 0, tx = 0;
   auto norm = [&]() {
     while (ci >= g.Cin) {
       ci -= g.Cin;
       if (++tx == g.ntx) { tx = 0; ++ty; }
     }
   };
-  norm();
+  if (!UNI) norm();
 
-  uint4 areg[A_IT], breg[B_IT];
-  auto load_stage = [&]() {
-    const bool kok = ty < g.nty;
+  // two register sets: the loads of stage t+2 are issued before the MFMAs of stage t, so a global
+  // load has two stages of MFMA time to land
+  uint4 areg[2][A_IT], breg[2][B_IT];
+  auto load_stage = [&](auto SET) {
+    constexpr int set = decltype(SET)::value;
+    if constexpr (UNI) {
+      // past the end of K the walk simply wraps to tap 0: the data is staged but never multiplied
+      const int wy = ty < g.nty ? ty : 0, wx = ty < g.nty ? tx : 0;
+      // tap displacement measured from the lowest pixel of the walk, so it is never negative
+      const int tp = wy * g.IW + wx;
+      const int adelta = (g.sign > 0 ? tp : (int)reach - tp) * pix_bytes + ci * (int)sizeof(T);
+      const int bdelta = (((g.ky0 + g.kstep * wy) * g.KW + (g.kx0 + g.kstep * wx)) * g.Cin + ci) * (int)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int iy = riy[i] + g.sign * ty, ix = rix[i] + g.sign * tx;
-      const bool ok = kok && rb[i] >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const size_t pix = ((size_t)rb[i] * g.IH + iy) * g.IW + ix;
-        v = *reinterpret_cast<const uint4*>(in + pix * g.in_cstride + g.in_coff + ci);
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = ((ymask[i] >> wy) & (xmask[i] >> wx) & 1u) != 0;
+        // adelta rides in the scalar offset: not part of the range check, added to the address
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? aoff[i] : OOB, adelta, 0);
+        areg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
       }
-      areg[i] = v;
-    }
-    const int wk = ((g.ky0 + g.kstep * ty) * g.KW + (g.kx0 + g.kstep * tx)) * g.Cin + ci;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int r = r0 + 32 * i;
-      const int n = n0 + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kok && r < BN && n < g.Cout) v = *reinterpret_cast<const uint4*>(wgt + (size_t)n * Ktot_w + wk);
-      breg[i] = v;
+      for (int i = 0; i < B_IT; ++i) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff[i], bdelta, 0);
+        breg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      ci += BK;
+      if (ci >= g.Cin) {   // Cin % BK == 0: exactly one wrap
+        ci = 0;
+        if (++tx == g.ntx) { tx = 0; ++ty; }
+      }
+    } else {
+      const bool kok = ty < g.nty;
+      const int tp = ty * g.IW + tx;
+      const unsigned adelta = (unsigned)((g.sign > 0 ? tp : (int)reach - tp) * pix_bytes + ci * (int)sizeof(T));
+      const unsigned bdelta = (unsigned)((((g.ky0 + g.kstep * ty) * g.KW + (g.kx0 + g.kstep * tx)) * g.Cin + ci) * (int)sizeof(T));
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = kok && ((ymask[i] >> ty) & (xmask[i] >> tx) & 1u);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? aoff[i] + adelta : OOB, 0, 0);
+        areg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(brsrc, (kok && boff[i] != OOB) ? boff[i] + bdelta : OOB, 0, 0);
+        breg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
+      }
+      ci += BK;  // stages are always loaded in order
+      norm();
     }
   };
-  auto store_stage = [&](int buf) {
+  char* const a_st = As + r0 * ROWB + ch * 16;   // + buf*AS_BYTES + i*32*ROWB: immediates
+  char* const b_st = Bs + r0 * ROWB + ch * 16;
+  auto store_stage = [&](auto SET, auto BUF) {
+    constexpr int set = decltype(SET)::value, buf = decltype(BUF)::value;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
-      *reinterpret_cast<uint4*>(As + (buf * BM + r0 + 32 * i) * ROWB + ch * 16) = areg[i];
+      *reinterpret_cast<uint4*>(a_st + buf * AS_BYTES + i * 32 * ROWB) = areg[set][i];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
-      if (r0 + 32 * i < BN) *reinterpret_cast<uint4*>(Bs + (buf * BN + r0 + 32 * i) * ROWB + ch * 16) = breg[i];
+      if (B_IT * 32 <= BN || r0 + 32 * i < BN)
+        *reinterpret_cast<uint4*>(b_st + buf * BS_BYTES + i * 32 * ROWB) = breg[set][i];
   };
-  auto advance = [&]() {
-    ci += BK;
-    norm();
-  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -153,54 +221,66 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 31, lh = lane >> 5;
+  const char* const a_ld = As + (wm * WTM + lr) * ROWB + lh * 16;
+  const char* const b_ld = Bs + (wn * WTN + lr) * ROWB + lh * 16;
 
-  if (KT > 0) {
-    load_stage();
-    store_stage(0);
-    advance();
-  }
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) load_stage();  // global loads for the next stage fly during the MFMAs below
-    const char* Ab = As + (buf * BM + wm * WTM + lr) * ROWB + lh * 16;
-    const char* Bb = Bs + (buf * BN + wn * WTN + lr) * ROWB + lh * 16;
+  auto compute = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
 #pragma unroll
     for (int s = 0; s < NCH / 2; ++s) {
       frag_t a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag_t*>(Ab + mi * 32 * ROWB + s * 32);
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag_t*>(a_ld + buf * AS_BYTES + mi * 32 * ROWB + s * 32);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const frag_t*>(Bb + ni * 32 * ROWB + s * 32);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const frag_t*>(b_ld + buf * BS_BYTES + ni * 32 * ROWB + s * 32);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) mma_chunk(acc[mi][ni], a[mi], b[ni]);
     }
-    if (more) {
-      store_stage(buf ^ 1);
-      advance();
-    }
+  };
+  // one pipeline step: [issue loads of stage t+2] -> MFMAs of stage t -> [stage t+1 regs -> LDS] -> barrier.
+  // Stage t lives in register set t&1 and LDS buffer t&1.  No conditionals inside a step, so hipcc
+  // counts the outstanding loads exactly and waits only for the older set (vmcnt(N), never a drain).
+  auto step = [&](auto CUR, auto NXT) {
+    load_stage(CUR);            // stage t+2 -> set CUR (stage t's copy is already in LDS buffer CUR)
+    compute(CUR);               // MFMAs of stage t
+    store_stage(NXT, NXT);      // stage t+1 -> LDS buffer NXT
     __syncthreads();
+  };
+  load_stage(S0{});
+  load_stage(S1{});
+  store_stage(S0{}, S0{});
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < KT; kt += 2) {
+    step(S0{}, S1{});
+    step(S1{}, S0{});
   }
+  if (kt < KT) step(S0{}, S1{});
 
-  // epilogue: C row = (e&3) + 8*(e>>2) + 4*lh, C col = lr
+  // epilogue: C row = (e&3) + 8*(e>>2) + 4*lh, C col = lr.  One pointer per output row.
+  float bv[NI];
+  int ncol[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * WTN + ni * 32 + lr;
-    if (n >= g.Cout) continue;
-    const float bv = bias ? bias[n] : 0.f;
+    ncol[ni] = n0 + wn * WTN + ni * 32 + lr;
+    bv[ni] = (bias && ncol[ni] < g.Cout) ? bias[ncol[ni]] : 0.f;
+  }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int opix = rows[row].opix;
-        if (opix < 0) continue;
-        float v = acc[mi][ni][e] + bv;
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const int opix = rows[row].opix;
+      if (opix < 0) continue;
+      T* orow = out + (size_t)opix * g.out_cstride + g.out_coff;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (ncol[ni] >= g.Cout) continue;
+        float v = acc[mi][ni][e] + bv[ni];
         if (g.relu) v = fmaxf(v, 0.f);
-        out[(size_t)opix * g.out_cstride + g.out_coff + n] = (T)v;
+        orow[ncol[ni]] = (T)v;
       }
     }
   }
@@ -213,14 +293,21 @@ int launch_cfg(const void* in, const void* wgt, const float* bias, void* out, co
   const long long nblk = ((M + BM - 1) / BM) * ((g.Cout + BN - 1) / BN);
   if (nblk > 0x7fffffffLL) return fail(JSPSR_EINVAL, "conv: grid too large");
   const size_t lds = 2 * (BM + BN) * ROWB + BM * sizeof(RowInfo);
-  auto kern = conv_igemm_kernel<T, BM, BN, WGM, WGN>;
+  constexpr int BK = NCH * Elem<T>::EPC;
   static bool attr_set = false;  // > 64 KiB dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BM, BN, WGM, WGN, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BM, BN, WGM, WGN, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, s, static_cast<const T*>(in),
-                     static_cast<const T*>(wgt), bias, static_cast<T*>(out), g);
+  if (g.Cin % BK == 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true>), dim3((unsigned)nblk), dim3(NT), lds, s,
+                       static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), g);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false>), dim3((unsigned)nblk), dim3(NT), lds, s,
+                       static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), g);
   return check_launch("conv_igemm");
 }
 

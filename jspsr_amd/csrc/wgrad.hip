@@ -257,7 +257,7 @@ int launch_w(const void* G, const void* X, float* ws, const WgradGeom& g, int sp
   auto kern = wgrad_kernel<T, BMC, BNC, WGM, WGN>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid((g.Cg + BMC - 1) / BMC, (g.Ktot + BNC - 1) / BNC, splits);

@@ -35,8 +35,13 @@ def timeit(fn, n=10):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-    for dtype in (torch.float32, torch.bfloat16):
-        for (B, H, W, Ci, Co, k, s) in SHAPES:
+    only = int(sys.argv[2]) if len(sys.argv) > 2 else None      # shape index
+    dts = (torch.bfloat16,) if len(sys.argv) > 3 and sys.argv[3] == "bf16" else (torch.float32, torch.bfloat16)
+    ours_only = len(sys.argv) > 4
+    for dtype in dts:
+        for si, (B, H, W, Ci, Co, k, s) in enumerate(SHAPES):
+            if only is not None and si != only:
+                continue
             pad = k // 2
             x = torch.randn(B, H, W, Ci, device="cuda").to(dtype)
             w = torch.randn(Co, Ci, k, k, device="cuda") / (Ci * k * k) ** 0.5
@@ -47,7 +52,7 @@ def main():
                 t = timeit(lambda: K.conv2d_forward(x, wp, None, s, pad))
                 xc = x.permute(0, 3, 1, 2)  # channels_last view
                 wc = w.to(dtype).contiguous(memory_format=torch.channels_last)
-                tm = timeit(lambda: F.conv2d(xc, wc, None, s, pad))
+                tm = float("nan") if ours_only else timeit(lambda: F.conv2d(xc, wc, None, s, pad))
             else:
                 go = torch.randn(B, OH, OW, Co, device="cuda").to(dtype)
                 wpt = K.pack_weight(w, 1, Co, dtype)
