@@ -15,6 +15,8 @@
 // order by a second kernel that also writes the master (R, C, KH, KW) fp32 layout -> bit-reproducible.
 #include "conv_igemm.h"
 
+#include <type_traits>
+
 namespace {
 
 using namespace jspsr;
@@ -50,11 +52,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
   constexpr int CPR_G = BMC / EPC, CPR_X = BNC / EPC;  // 16-byte chunks per tile row
   constexpr int G_IT = (BKM * CPR_G + NT - 1) / NT, X_IT = BKM * CPR_X / NT;
   constexpr int G_RSTEP = NT / CPR_G, X_RSTEP = NT / CPR_X;
+  constexpr int GS_BYTES = BKM * GP, XS_BYTES = BKM * XP;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
   static_assert(WGM * WGN == 4 && MI >= 1 && NI >= 1 && NT % CPR_G == 0 && NT % CPR_X == 0, "tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Gs = smem;                    // [2][BKM][GP]
-  char* Xs = smem + 2 * BKM * GP;     // [2][BKM][XP]
+  char* Xs = smem + 2 * GS_BYTES;     // [2][BKM][XP]
 
   const int tid = threadIdx.x;
   const int co0 = blockIdx.x * BMC, n0 = blockIdx.y * BNC;
@@ -62,17 +66,44 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
   const long long m_end = (m_begin + g.m_per_split < g.M) ? m_begin + g.m_per_split : g.M;
   const int KT = (int)((m_end - m_begin + BKM - 1) / BKM);
 
-  // G staging: chunk gc of rows gr0 + i*G_RSTEP
+  // ---- G: rows are linear in m.  Descriptor base = first row of this slice, range = the slice:
+  // rows past m_end are out of range and come back as zeros (which also silences the X rows there).
   const int gc = tid % CPR_G, gr0 = tid / CPR_G;
-  const bool g_colok = co0 + gc * EPC < g.Cg;
-  // X staging: chunk xc (a fixed (tap, channel) column group) of rows xr0 + i*X_RSTEP
+  const int g_row_bytes = g.g_cs * (int)sizeof(T);
+  const char* gbase = reinterpret_cast<const char*>(G) + ((size_t)m_begin * g.g_cs + g.g_coff) * sizeof(T);
+  const unsigned g_range = (unsigned)((m_end - m_begin) * (long long)g_row_bytes);
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase), 0, g_range, 0x00020000);
+  unsigned goff[G_IT];
+#pragma unroll
+  for (int i = 0; i < G_IT; ++i) {
+    const int r = gr0 + i * G_RSTEP;
+    goff[i] = (r < BKM && co0 + gc * EPC < g.Cg) ? (unsigned)(r * g_row_bytes + (co0 + gc * EPC) * (int)sizeof(T)) : OOB;
+  }
+
+  // ---- X: chunk xc is a fixed (tap, channel) column group; rows walk the output grid.
   const int xc = tid % CPR_X, xr0 = tid / CPR_X;
   const int kcol = n0 + xc * EPC;
   const bool x_colok = kcol < g.Ktot;
   const int tap = x_colok ? kcol / g.Cx : 0, cix = x_colok ? kcol % g.Cx : 0;
   const int ky = tap / g.KW, kx = tap % g.KW;
-  // pixel coordinates of this thread's X rows, advanced incrementally per stage
-  int xb[X_IT], xoy[X_IT], xox[X_IT];
+  const int x_pix_bytes = g.x_cs * (int)sizeof(T);
+  const long long b_first = m_begin / ((long long)g.OH * g.OW);
+  const char* xbase = reinterpret_cast<const char*>(X) + ((size_t)b_first * g.IH * g.IW * g.x_cs + g.x_coff) * sizeof(T);
+  const long long x_left = ((long long)g.B - b_first) * g.IH * g.IW * (long long)x_pix_bytes;
+  const unsigned x_range = x_left > 0xFFFFFF00LL ? 0xFFFFFF00u : (unsigned)x_left;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, x_range, 0x00020000);
+  // per row: output coords, byte offset of input row (iy, ix = kx - pad) and its validity
+  int xoy[X_IT], xox[X_IT], xb[X_IT];
+  unsigned xrow[X_IT];   // may be "negative" (mod 2^32) when kx < pad; adding a valid ix brings it back
+  bool xrow_ok[X_IT];
+  auto row_setup = [&](int i) {
+    const int iy = xoy[i] * g.stride - g.pad + ky;
+    const long long pix = ((long long)(xb[i] - b_first) * g.IH + iy) * g.IW + (kx - g.pad);
+    const long long off = pix * x_pix_bytes + cix * (long long)sizeof(T);
+    xrow_ok[i] = x_colok && (unsigned)iy < (unsigned)g.IH && xb[i] < g.B &&
+                 off + (long long)g.IW * x_pix_bytes < 0xFFFFFF00LL;
+    xrow[i] = (unsigned)off;
+  };
 #pragma unroll
   for (int i = 0; i < X_IT; ++i) {
     const long long m = m_begin + xr0 + i * X_RSTEP;
@@ -80,48 +111,53 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
     const long long tq = m / g.OW;
     xoy[i] = (int)(tq % g.OH);
     xb[i] = (int)(tq / g.OH);
+    row_setup(i);
   }
 
-  uint4 greg[G_IT], xreg[X_IT];
-  auto load_stage = [&](int kt) {
-    const long long mb = m_begin + (long long)kt * BKM;
+  uint4 greg[2][G_IT], xreg[2][X_IT];
+  int g_soff = 0;   // scalar: advances by one stage of rows
+  auto load_stage = [&](auto SET) {
+    constexpr int set = decltype(SET)::value;
 #pragma unroll
     for (int i = 0; i < G_IT; ++i) {
-      const int r = gr0 + i * G_RSTEP;
-      const long long m = mb + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (g_colok && r < BKM && m < m_end)
-        v = *reinterpret_cast<const uint4*>(G + (size_t)m * g.g_cs + g.g_coff + co0 + gc * EPC);
-      greg[i] = v;
+      // the range check covers voffset only; rows past the slice are caught by folding the stage
+      // advance into voffset when it would leave the range
+      const unsigned off = goff[i] == OOB ? OOB : goff[i] + (unsigned)g_soff;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off, 0, 0);
+      greg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
+    g_soff += BKM * g_row_bytes;
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
-      const long long m = mb + xr0 + i * X_RSTEP;
-      const int iy = xoy[i] * g.stride - g.pad + ky, ix = xox[i] * g.stride - g.pad + kx;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (x_colok && m < m_end && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) {
-        const size_t pix = ((size_t)xb[i] * g.IH + iy) * g.IW + ix;
-        v = *reinterpret_cast<const uint4*>(X + pix * g.x_cs + g.x_coff + cix);
-      }
-      xreg[i] = v;
-      // advance this row by one stage (BKM pixels) for the next call
-      xox[i] += BKM;
-      while (xox[i] >= g.OW) {
-        xox[i] -= g.OW;
-        if (++xoy[i] == g.OH) { xoy[i] = 0; ++xb[i]; }
+      const int ix = xox[i] * g.stride - g.pad + kx;
+      const bool ok = xrow_ok[i] && (unsigned)ix < (unsigned)g.IW;
+      const unsigned off = ok ? xrow[i] + (unsigned)(xox[i] * g.stride * x_pix_bytes) : OOB;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+      xreg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
+      xox[i] += BKM;               // advance this row by one stage of pixels
+      if (xox[i] >= g.OW) {
+        do {
+          xox[i] -= g.OW;
+          if (++xoy[i] == g.OH) { xoy[i] = 0; ++xb[i]; }
+        } while (xox[i] >= g.OW);
+        row_setup(i);
       }
     }
   };
-  auto store_stage = [&](int buf) {
+  char* const g_st = Gs + gr0 * GP + gc * 16;
+  char* const x_st = Xs + xr0 * XP + xc * 16;
+  auto store_stage = [&](auto SET, auto BUF) {
+    constexpr int set = decltype(SET)::value, buf = decltype(BUF)::value;
 #pragma unroll
-    for (int i = 0; i < G_IT; ++i) {
-      const int r = gr0 + i * G_RSTEP;
-      if (r < BKM) *reinterpret_cast<uint4*>(Gs + (buf * BKM + r) * GP + gc * 16) = greg[i];
-    }
+    for (int i = 0; i < G_IT; ++i)
+      if (G_IT * G_RSTEP <= BKM || gr0 + i * G_RSTEP < BKM)
+        *reinterpret_cast<uint4*>(g_st + buf * GS_BYTES + i * G_RSTEP * GP) = greg[set][i];
 #pragma unroll
     for (int i = 0; i < X_IT; ++i)
-      *reinterpret_cast<uint4*>(Xs + (buf * BKM + xr0 + i * X_RSTEP) * XP + xc * 16) = xreg[i];
+      *reinterpret_cast<uint4*>(x_st + buf * XS_BYTES + i * X_RSTEP * XP) = xreg[set][i];
   };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -134,28 +170,26 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 31, lh = lane >> 5;
+  // transposing reads (bf16): lane (4q+p) of a 16-lane group addresses row q, columns 4p..4p+3 of a
+  // 4-pixel x 16-channel block and receives column (lane&15) of the 4 rows.
+  const int grp16 = (lane >> 4) & 1, li = lane & 15, q = li >> 2, pp = li & 3;
+  const char* const g_ld = sizeof(T) == 4 ? Gs + lh * GP + (wm * WTM + lr) * 4
+                                           : Gs + (8 * lh + q) * GP + (wm * WTM + 16 * grp16 + 4 * pp) * 2;
+  const char* const x_ld = sizeof(T) == 4 ? Xs + lh * XP + (wn * WTN + lr) * 4
+                                           : Xs + (8 * lh + q) * XP + (wn * WTN + 16 * grp16 + 4 * pp) * 2;
 
-  if (KT > 0) {
-    load_stage(0);
-    store_stage(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) load_stage(kt + 1);
-    const char* Gb = Gs + buf * BKM * GP;
-    const char* Xb = Xs + buf * BKM * XP;
+  auto compute = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
     if constexpr (sizeof(T) == 4) {
 #pragma unroll 4
       for (int s = 0; s < BKM / 2; ++s) {
         float a[MI], b[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          a[mi] = *reinterpret_cast<const float*>(Gb + (2 * s + lh) * GP + (wm * WTM + mi * 32 + lr) * 4);
+          a[mi] = *reinterpret_cast<const float*>(g_ld + buf * GS_BYTES + 2 * s * GP + mi * 32 * 4);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          b[ni] = *reinterpret_cast<const float*>(Xb + (2 * s + lh) * XP + (wn * WTN + ni * 32 + lr) * 4);
+          b[ni] = *reinterpret_cast<const float*>(x_ld + buf * XS_BYTES + 2 * s * XP + ni * 32 * 4);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -163,23 +197,19 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
       }
     } else {
-      // transposing reads: lane (4q+p) of a 16-lane group addresses row q, columns 4p..4p+3 of a
-      // 4-pixel x 16-channel block and receives column (lane&15) of the 4 rows.
-      const int grp16 = (lane >> 4) & 1, li = lane & 15, q = li >> 2, pp = li & 3;
 #pragma unroll
       for (int kb = 0; kb < BKM / 16; ++kb) {
         bf16x8 a[MI], b[NI];
-        const int row0 = kb * 16 + 8 * lh + q;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          const char* p = Gb + row0 * GP + (wm * WTM + mi * 32 + 16 * grp16 + 4 * pp) * 2;
+          const char* p = g_ld + buf * GS_BYTES + kb * 16 * GP + mi * 32 * 2;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * GP));
           a[mi] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          const char* p = Xb + row0 * XP + (wn * WTN + ni * 32 + 16 * grp16 + 4 * pp) * 2;
+          const char* p = x_ld + buf * XS_BYTES + kb * 16 * XP + ni * 32 * 2;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * XP));
           b[ni] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -191,9 +221,25 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
       }
     }
-    if (more) store_stage(buf ^ 1);
+  };
+  // [loads of stage t+2] -> MFMAs of stage t -> [stage t+1 regs -> LDS] -> barrier; branch-free so
+  // the compiler's vmcnt waits are exact counts (see conv.hip)
+  auto step = [&](auto CUR, auto NXT) {
+    load_stage(CUR);
+    compute(CUR);
+    store_stage(NXT, NXT);
     __syncthreads();
+  };
+  load_stage(S0{});
+  load_stage(S1{});
+  store_stage(S0{}, S0{});
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < KT; kt += 2) {
+    step(S0{}, S1{});
+    step(S1{}, S0{});
   }
+  if (kt < KT) step(S0{}, S1{});
 
   float* slab = ws + (size_t)blockIdx.z * g.Cg * g.Ktot;
 #pragma unroll
@@ -210,22 +256,24 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
   }
 }
 
-// dW[r][c][ky][kx] (+)= sum_z ws[z][r][(ky*KW+kx)*Cx + c],  r < R, c < C  (fixed summation order)
+// dW[r][c][ky][kx] (+)= sum_z ws[z][r][(ky*KW+kx)*Cx + c],  r < R, c < C  (fixed summation order).
+// Threads walk the slab layout (coalesced reads of every slab); the scattered 4-byte writes into the
+// (R, C, KH, KW) master layout are the small side.
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int R, int C, int KH,
                                     int KW, int Cg, int Cx, int splits, int accumulate) {
-  const long long total = (long long)R * C * KH * KW;
-  const size_t slab = (size_t)Cg * KH * KW * Cx;
+  const int Ktot = KH * KW * Cx;
+  const long long total = (long long)R * Ktot;
+  const size_t slab = (size_t)Cg * Ktot;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    long long t = idx;
-    const int kx = (int)(t % KW); t /= KW;
-    const int ky = (int)(t % KH); t /= KH;
-    const int c = (int)(t % C);
-    const int r = (int)(t / C);
-    const size_t src = (size_t)r * KH * KW * Cx + (size_t)(ky * KW + kx) * Cx + c;
+    const int r = (int)(idx / Ktot), k = (int)(idx % Ktot);
+    const int tap = k / Cx, c = k % Cx;
+    if (c >= C) continue;
+    const size_t src = (size_t)r * Ktot + k;
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += ws[z * slab + src];
-    dW[idx] = accumulate ? dW[idx] + s : s;
+    const size_t dst = ((size_t)r * C + c) * (KH * KW) + tap;
+    dW[dst] = accumulate ? dW[dst] + s : s;
   }
 }
 
@@ -239,7 +287,7 @@ Plan make_plan(long long M, int Cg, int Ktot) {
   p.bmc = Cg > 64 ? 128 : (Cg > 32 ? 64 : 32);
   const int BKM = WT<T>::BKM;
   const long long tiles = (long long)((Cg + p.bmc - 1) / p.bmc) * ((Ktot + 127) / 128);
-  long long splits = (1024 + tiles - 1) / tiles;        // aim at ~4 workgroups per CU
+  long long splits = (768 + tiles - 1) / tiles;         // aim at ~3 workgroups per CU
   const long long max_splits = (M + 4 * BKM - 1) / (4 * BKM);  // >= 4 stages per slice
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -269,12 +317,18 @@ template <typename T>
 int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradGeom& g, int accumulate, hipStream_t s) {
   const Plan p = make_plan<T>(g.M, g.Cg, g.Ktot);
   g.m_per_split = p.m_per_split;
+  // 32-bit buffer offsets: one slice of G, and the images of X one slice touches, must stay < 3.75 GiB
+  const long long g_slice = (long long)p.m_per_split * g.g_cs * (long long)sizeof(T);
+  const long long imgs = p.m_per_split / ((long long)g.OH * g.OW) + 2;
+  const long long x_span = imgs * g.IH * g.IW * (long long)g.x_cs * (long long)sizeof(T);
+  if (g_slice >= 0xF0000000LL || (x_span >= 0xF0000000LL && (long long)g.B * g.IH * g.IW * g.x_cs * (long long)sizeof(T) >= 0xF0000000LL))
+    return fail(JSPSR_EINVAL, "conv2d_wgrad: tensor slice exceeds the 32-bit offset range of one launch");
   int e;
   if (p.bmc == 128) e = launch_w<T, 128, 2, 2>(G, X, ws, g, p.splits, s);
   else if (p.bmc == 64) e = launch_w<T, 64, 2, 2>(G, X, ws, g, p.splits, s);
   else e = launch_w<T, 32, 1, 4>(G, X, ws, g, p.splits, s);
   if (e) return e;
-  const long long total = (long long)R * C * g.KH * g.KW;
+  const long long total = (long long)R * g.Ktot;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dW, R, C, g.KH, g.KW, g.Cg, g.Cx,
                      p.splits, accumulate);
