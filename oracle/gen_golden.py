@@ -170,6 +170,69 @@ def gen_model(ref_jspsr, path, in_channels, nf, B, H, W, seed, training):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def _store_grads(model, store, save):
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(p.grad.norm().item())
+        if k in save:
+            store["grad:" + k] = p.grad.numpy()
+    store["grad_names"] = np.array(names)
+    store["grad_norms"] = np.array(norms)
+
+
+def gen_lrru(path, B, H, W, seed, training):
+    """models.LRRU.Model (4 propagation steps), fp64, deterministic StoDepth (prob = 1)."""
+    import models.LRRU as ref_lrru
+    shapes = R.lrru_param_shapes(16)
+    sd = R.make_state_dict(shapes, seed, torch.float64)
+    args = types.SimpleNamespace(input_channels={"lr_dem": 1, "image": 3}, output_channels=1, kernel_size=3,
+                                 bc=16, prob=1.0, dkn_residual=True)
+    np.random.seed(0)
+    model = ref_lrru.Model(args)
+    assert [(k, tuple(v.shape)) for k, v in model.state_dict().items()] == list(shapes.items())
+    model = model.double()
+    model.load_state_dict(sd, strict=True)
+    model.train(training)
+    inputs, gt = R.synthetic_batch(B, H, W, False, seed=seed + 1, dtype=torch.float64)
+    pred = model(*inputs)
+    loss = ((pred - gt) ** 2).mean()
+    store = {"pred": pred.detach().numpy(), "loss": np.float64(loss.item()), "seed": np.int64(seed),
+             "BHW": np.array([B, H, W]), "training": np.bool_(training),
+             "param_abs_sum": np.float64(sum(v.double().abs().sum().item() for v in sd.values()))}
+    if training:
+        loss.backward()
+        _store_grads(model, store, ("weight_offset3.conv_weight.weight", "Post_process.w", "weight_offset3.convf1.conv.0.weight"))
+    np.savez(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_edsr(path, B, H, W, seed, training):
+    """models.EDSR.EDSR(scale=1, spn=True) on cat(dem, image), fp64."""
+    import models.EDSR as ref_edsr
+    shapes = R.edsr_param_shapes(4, 4, 32)
+    sd = R.make_state_dict(shapes, seed, torch.float64)
+    model = ref_edsr.EDSR(in_channels=4, out_channels=1, n_resblocks=4, n_features=32, scale=1, spn=True)
+    assert [(k, tuple(v.shape)) for k, v in model.state_dict().items()] == list(shapes.items())
+    model = model.double()
+    model.load_state_dict(sd, strict=True)
+    model.train(training)
+    inputs, gt = R.synthetic_batch(B, H, W, False, seed=seed + 1, dtype=torch.float64)
+    x = torch.cat(inputs, 1)
+    pred = model(x)
+    loss = ((pred - gt) ** 2).mean()
+    store = {"pred": pred.detach().numpy(), "loss": np.float64(loss.item()), "seed": np.int64(seed),
+             "BHW": np.array([B, H, W]), "training": np.bool_(training),
+             "param_abs_sum": np.float64(sum(v.double().abs().sum().item() for v in sd.values()))}
+    if training:
+        loss.backward()
+        _store_grads(model, store, ("entry.weight", "generator.conv_weight.0.weight", "post_layer.w"))
+    np.savez(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref_jspsr, ref_spn = import_reference()
     out = os.path.join(REPO, "tests", "golden")
@@ -182,6 +245,9 @@ def main():
     gen_model(ref_jspsr, os.path.join(out, "g3_img_nf8_b2_48x80_train.npz"), img, 8, 2, 48, 80, 12, True)
     gen_model(ref_jspsr, os.path.join(out, "g4_msk_nf8_b2_64_train.npz"), msk, 8, 2, 64, 64, 13, True)
     gen_model(ref_jspsr, os.path.join(out, "g4_msk_nf8_b2_64_eval.npz"), msk, 8, 2, 64, 64, 13, False)
+    gen_lrru(os.path.join(out, "g5_lrru_b1_64_train.npz"), 1, 64, 64, 21, True)
+    gen_lrru(os.path.join(out, "g5_lrru_b2_32x48_eval.npz"), 2, 32, 48, 22, False)
+    gen_edsr(os.path.join(out, "g6_edsr_b2_40x56_train.npz"), 2, 40, 56, 31, True)
 
 
 if __name__ == "__main__":

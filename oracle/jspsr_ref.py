@@ -450,3 +450,212 @@ def multi_loss(pred, gt, w_l1=1.0, w_l2=1.0, w_grad=0.1):
     l2 = ((pred - gt) ** 2).mean()
     ge = (sobel_gradient(pred) - sobel_gradient(gt)).abs().mean()
     return {"L1": l1, "L2": l2, "Grad": ge, "Total": w_l1 * l1 + w_l2 * l2 + w_grad * ge}
+
+
+# --------------------------------------------------------------------------------------
+# LRRU baseline re-targeted to DEMs (models/LRRU.py:301-507): 4 propagation steps
+# --------------------------------------------------------------------------------------
+
+
+def lrru_param_shapes(bc: int = 16, layers=(2, 2, 2, 2, 2)) -> Dict[str, tuple]:
+    """state_dict shapes of models.LRRU.Model(args) with args.bc = bc, in the reference's order."""
+    out: Dict[str, tuple] = {}
+    c = bc * 2
+
+    def conv(name, co, ci, k, bias):
+        out[name + ".weight"] = (co, ci, k, k)
+        if bias:
+            out[name + ".bias"] = (co,)
+
+    def bn(name, ch):
+        for s, shp in (("weight", (ch,)), ("bias", (ch,)), ("running_mean", (ch,)), ("running_var", (ch,)),
+                       ("num_batches_tracked", ())):
+            out[f"{name}.{s}"] = shp
+
+    def b2d(name, ci, co, k, norm):
+        conv(name + ".conv.0", co, ci, k, not norm)
+        if norm:
+            bn(name + ".conv.bn", co)
+
+    def block(name, ci, co, down):
+        conv(name + ".conv1", co, ci, 3, False)
+        bn(name + ".bn1", co)
+        conv(name + ".conv2", co, co, 3, False)
+        bn(name + ".bn2", co)
+        if down:
+            conv(name + ".downsample.0", co, ci, 1, False)
+            bn(name + ".downsample.1", co)
+
+    def trans(name, ci, co):
+        out[name + ".conv.weight"] = (ci, co, 3, 3)
+        bn(name + ".bn", co)
+
+    def enc(name):
+        b2d(name + ".convd1", 1, c, 3, False)
+        b2d(name + ".convd2", c, c, 3, False)
+        b2d(name + ".convf1", c, c, 3, False)
+        b2d(name + ".convf2", c, c, 3, False)
+        b2d(name + ".conv", 2 * c, 2 * c, 3, False)
+        block(name + ".ref", 2 * c, 2 * c, False)
+        conv(name + ".conv_weight", 9, 2 * c, 1, True)
+        conv(name + ".conv_offset", 16, 2 * c, 1, True)
+
+    b2d("conv_img", 3, c, 5, True)
+    b2d("conv_lidar", 1, c, 5, False)
+    planes = [2 * c, 4 * c, 8 * c, 8 * c, 8 * c]
+    inpl = c
+    for s in range(5):
+        stride = 1 if s == 0 else 2
+        for br in ("img", "lidar"):
+            for i in range(layers[s]):
+                ci = inpl if i == 0 else planes[s]
+                block(f"layer{s + 1}_{br}.{i}", ci, planes[s], i == 0 and (stride != 1 or inpl != planes[s]))
+        if s < 4:
+            b2d(f"guide{s + 1}.conv", planes[s] * 2, planes[s], 3, True)
+        inpl = planes[s]
+    trans("layer4d", 8 * c, 8 * c)
+    for i, (ci, co) in enumerate(((8 * c, 4 * c), (4 * c, 2 * c), (2 * c, c))):
+        trans(f"upproj0.{i}", ci, co)
+    enc("weight_offset0")
+    trans("layer3d", 8 * c, 8 * c)
+    for i, (ci, co) in enumerate(((8 * c, 4 * c), (4 * c, c))):
+        trans(f"upproj1.{i}", ci, co)
+    enc("weight_offset1")
+    trans("layer2d", 8 * c, 4 * c)
+    trans("upproj2.0", 4 * c, c)
+    enc("weight_offset2")
+    trans("layer1d", 4 * c, 2 * c)
+    b2d("conv", 2 * c, c, 3, True)
+    enc("weight_offset3")
+    out["Post_process.w"] = (1, 1, 3, 3)
+    out["Post_process.b"] = (1,)
+    return out
+
+
+def lrru_forward(sd: SD, inputs: Sequence[torch.Tensor], training: bool, layers=(2, 2, 2, 2, 2)):
+    """models.LRRU.Model.forward (LRRU.py:403-507) with prob = 1 (deterministic StoDepth blocks)."""
+    c = Ctx(sd, training)
+    if len(inputs) != 2:
+        raise NotImplementedError
+    depth, img = inputs
+
+    def b2d(x, p, k=3, norm=False):
+        return basic2d(c, x, p, k, bn=norm, relu=True)
+
+    def trans(x, p):  # Basic2dTrans, LRRU.py:67-88
+        y = F.conv_transpose2d(x, c[p + ".conv.weight"], None, 2, 1, 1)
+        return F.relu(batch_norm(c, y, p + ".bn"))
+
+    def guide(feat, weight, p):  # LRRU.py:188-200
+        return b2d(torch.cat((feat, weight), 1), p + ".conv", 3, True)
+
+    def encoder(depth_, ctx_, p):  # BasicDepthEncoder.forward, LRRU.py:226-247
+        B, _, H, W = depth_.shape
+        d = b2d(b2d(depth_, p + ".convd1"), p + ".convd2")
+        f = b2d(b2d(ctx_, p + ".convf1"), p + ".convf2")
+        x = b2d(torch.cat((d, f), 1), p + ".conv")
+        x = basic_block(c, x, p + ".ref", act=False)
+        weight = torch.sigmoid(F.conv2d(x, c[p + ".conv_weight.weight"], c[p + ".conv_weight.bias"]))
+        off16 = F.conv2d(x, c[p + ".conv_offset.weight"], c[p + ".conv_offset.bias"])
+        zero = torch.zeros(B, 2, H, W, dtype=off16.dtype)
+        return weight, torch.cat((off16[:, :8], zero, off16[:, 8:]), 1)
+
+    def post(d, w, o):  # Post_process_deconv.forward, LRRU.py:267-298
+        return propagate(d, w, o, sd["Post_process.w"], sd["Post_process.b"], 1.0)
+
+    def keep_input(out):  # preserve_input blend, LRRU.py:447-450 etc.
+        mask = ((depth > 0.0).sum(1, keepdim=True) > 0.0).to(depth.dtype)
+        return (1.0 - mask) * out + mask * depth
+
+    c0_img = b2d(img, "conv_img", 5, True)
+    c0_lidar = b2d(depth, "conv_lidar", 5, False)
+    fi, fl = c0_img, c0_lidar
+    dyn = []
+    for s in range(5):
+        stride = 1 if s == 0 else 2
+        fi = layer(c, fi, f"layer{s + 1}_img", layers[s], stride)
+        fl = layer(c, fl, f"layer{s + 1}_lidar", layers[s], stride)
+        if s < 4:
+            fl = guide(fl, fi, f"guide{s + 1}")
+            dyn.append(fl)
+    c5 = fi + fl
+    c4 = trans(c5, "layer4d") + dyn[3]
+    up = c4
+    for i in range(3):
+        up = trans(up, f"upproj0.{i}")
+    lidar = keep_input(depth).detach()
+    out = post(lidar, *encoder(lidar, up, "weight_offset0"))
+    c3 = trans(c4, "layer3d") + dyn[2]
+    up = trans(trans(c3, "upproj1.0"), "upproj1.1")
+    out = keep_input(out).detach()
+    out = post(out, *encoder(out, up, "weight_offset1"))
+    c2 = trans(c3, "layer2d") + dyn[1]
+    up = trans(c2, "upproj2.0")
+    out = keep_input(out).detach()
+    out = post(out, *encoder(out, up, "weight_offset2"))
+    c1 = trans(c2, "layer1d") + dyn[0]
+    c0 = b2d(c1, "conv", 3, True) + c0_lidar
+    out = keep_input(out).detach()
+    return post(out, *encoder(out, c0, "weight_offset3"))
+
+
+# --------------------------------------------------------------------------------------
+# EDSR trunk + the same generator / propagation head (models/EDSR.py:66-137, spn=True)
+# --------------------------------------------------------------------------------------
+
+
+def edsr_param_shapes(in_channels: int, n_resblocks=16, n_features=64) -> Dict[str, tuple]:
+    out: Dict[str, tuple] = {}
+    F_ = n_features
+
+    def conv(name, co, ci, k):
+        out[name + ".weight"] = (co, ci, k, k)
+        out[name + ".bias"] = (co,)
+
+    conv("entry", F_, in_channels, 3)
+    for i in range(n_resblocks):
+        conv(f"encoder.{i}.body.0", F_, F_, 3)
+        conv(f"encoder.{i}.body.2", F_, F_, 3)
+    conv(f"encoder.{n_resblocks}", F_, F_, 3)
+    g, bc = "generator", F_ // 2
+    for name, ci, co in ((".convd1", 1, bc * 2), (".convd2", bc * 2, bc * 2), (".convf1", F_, bc * 2),
+                         (".convf2", bc * 2, bc * 2), (".conv", bc * 4, bc * 4)):
+        conv(g + name + ".conv.0", co, ci, 3)
+    for nm in ("conv1", "conv2"):
+        out[f"{g}.block.{nm}.weight"] = (bc * 4, bc * 4, 3, 3)
+        for s, shp in (("weight", (bc * 4,)), ("bias", (bc * 4,)), ("running_mean", (bc * 4,)),
+                       ("running_var", (bc * 4,)), ("num_batches_tracked", ())):
+            out[f"{g}.block.bn{nm[-1]}.{s}"] = shp
+    # reference order inside BasicBlock: conv1, bn1, conv2, bn2
+    ordered = {}
+    for k in list(out):
+        if k.startswith(g + ".block."):
+            ordered[k] = out.pop(k)
+    for nm in ("1", "2"):
+        ordered_keys = [f"{g}.block.conv{nm}.weight"] + [f"{g}.block.bn{nm}.{s}" for s in
+                        ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
+        for k in ordered_keys:
+            out[k] = ordered[k]
+    out[g + ".conv_weight.0.weight"] = (9, bc * 4, 1, 1)
+    out[g + ".conv_weight.0.bias"] = (9,)
+    out[g + ".conv_offset.conv.0.weight"] = (16, bc * 4, 1, 1)
+    out[g + ".conv_offset.conv.0.bias"] = (16,)
+    out["post_layer.w"] = (1, 1, 3, 3)
+    out["post_layer.b"] = (1,)
+    return out
+
+
+def edsr_forward(sd: SD, x: torch.Tensor, training: bool, n_resblocks=16, res_scale=0.1):
+    """EDSR.forward with scale=1, spn=True (EDSR.py:123-137); x = cat(dem, guides) (B,C,H,W)."""
+    c = Ctx(sd, training)
+    dem = x[:, 0:1].detach()
+    xs = F.conv2d(x, sd["entry.weight"], sd["entry.bias"], 1, 1)
+    h = xs
+    for i in range(n_resblocks):  # ResBlock.forward, EDSR.py:40-44
+        r = F.conv2d(h, sd[f"encoder.{i}.body.0.weight"], sd[f"encoder.{i}.body.0.bias"], 1, 1)
+        r = F.conv2d(F.relu(r), sd[f"encoder.{i}.body.2.weight"], sd[f"encoder.{i}.body.2.bias"], 1, 1)
+        h = r * res_scale + h
+    h = F.conv2d(h, sd[f"encoder.{n_resblocks}.weight"], sd[f"encoder.{n_resblocks}.bias"], 1, 1)
+    h = h + res_scale * xs
+    weight, offset = generator(c, dem, h)
+    return propagate(dem, weight, offset, sd["post_layer.w"], sd["post_layer.b"], 1.0)

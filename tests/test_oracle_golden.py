@@ -166,3 +166,49 @@ def test_wrong_arity_raises():
     x = torch.zeros(1, 1, 16, 16)
     with pytest.raises(NotImplementedError):
         R.jspsr_forward(sd, [x], False)
+
+
+def _regen_simple(z, shapes, with_mask=False):
+    seed = int(z["seed"])
+    B, H, W = (int(v) for v in z["BHW"])
+    sd = R.make_state_dict(shapes, seed, torch.float64)
+    s1 = sum(v.double().abs().sum().item() for v in sd.values())
+    if abs(s1 - float(z["param_abs_sum"])) > 1e-9 * s1:
+        pytest.skip("torch CPU generator stream differs from the fixture's")
+    inputs, gt = R.synthetic_batch(B, H, W, with_mask, seed=seed + 1, dtype=torch.float64)
+    return sd, inputs, gt
+
+
+def _check_grads(z, params):
+    for k, n in zip(z["grad_names"], z["grad_norms"]):
+        got = params[str(k)].grad.norm().item()
+        assert abs(got - n) <= 1e-8 * max(n, 1e-30) + 1e-13, (k, got, n)
+    for k in z.files:
+        if k.startswith("grad:"):
+            assert torch.allclose(params[k[5:]].grad, _t(z[k]), rtol=1e-8, atol=1e-12), k
+
+
+@pytest.mark.parametrize("name", ["g5_lrru_b1_64_train.npz", "g5_lrru_b2_32x48_eval.npz"])
+def test_lrru_fp64(golden_dir, name):
+    """models.LRRU.Model (4 propagation steps, LRRU.py:403-507) restated."""
+    z = _load(golden_dir, name)
+    sd, inputs, gt = _regen_simple(z, R.lrru_param_shapes(16))
+    params = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    sd.update(params)
+    pred = R.lrru_forward(sd, inputs, bool(z["training"]))
+    assert torch.allclose(pred.detach(), _t(z["pred"]), rtol=0, atol=1e-11)
+    if bool(z["training"]):
+        ((pred - gt) ** 2).mean().backward()
+        _check_grads(z, params)
+
+
+def test_edsr_fp64(golden_dir):
+    """models.EDSR.EDSR(scale=1, spn=True) (EDSR.py:123-137) restated."""
+    z = _load(golden_dir, "g6_edsr_b2_40x56_train.npz")
+    sd, inputs, gt = _regen_simple(z, R.edsr_param_shapes(4, 4, 32))
+    params = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    sd.update(params)
+    pred = R.edsr_forward(sd, torch.cat(inputs, 1), True, n_resblocks=4)
+    assert torch.allclose(pred.detach(), _t(z["pred"]), rtol=0, atol=1e-11)
+    ((pred - gt) ** 2).mean().backward()
+    _check_grads(z, params)
