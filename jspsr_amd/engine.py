@@ -14,6 +14,7 @@ from . import kernels as K
 from . import ops
 
 _compute_dtype = torch.float32
+_gate_sync = None   # set by jspsr_amd.tiling during sharded inference (scene-wide gate statistics)
 
 
 class compute_dtype:
@@ -76,6 +77,10 @@ def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, res_scale
 
 def channel_gate(x, w1, w2):
     """x * sigmoid(MLP(avgpool x) + MLP(maxpool x)), resnet_cbam.py:49-53 + basics.py:57-58."""
+    if _gate_sync is not None:   # sharded inference: pooled statistics come from all strips
+        avg, mx = _gate_sync.pool(x.contiguous())
+        s = ops._gate_mlp(avg, mx, w1.detach().float(), w2.detach().float()).contiguous()
+        return K.gate_scale(x.contiguous(), s)
     return ops.channel_gate(x, w1, w2)
 
 

@@ -1,0 +1,51 @@
+"""CPU: strip planning and the neighbour halo exchange (gloo, world size 3)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_plan_strips_cover_scene():
+    from jspsr_amd.tiling import plan_strips
+    for H, world, halo in ((4096, 8, 128), (1024, 4, 128), (512, 3, 64), (256, 2, 128)):
+        s = plan_strips(H, world, halo)
+        assert s[0].y0 == 0 and s[-1].y1 == H
+        for a, b in zip(s[:-1], s[1:]):
+            assert a.y1 == b.y0
+        for t in s:
+            assert 0 <= t.ty0 <= t.y0 and t.y1 <= t.ty1 <= H and (t.ty1 - t.ty0) % 8 == 0
+            assert len({x.ty1 - x.ty0 for x in s}) == 1            # equal windows
+            assert t.y0 == 0 or t.y0 - t.ty0 >= min(halo, t.y0)    # halo towards every interior edge
+            assert t.y1 == H or t.ty1 - t.y1 >= min(halo, H - t.y1)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jspsr_amd.tiling import exchange_halo
+    scene = torch.arange(2 * 48 * 5, dtype=torch.float32).reshape(1, 2, 48, 5)
+    mine = scene[:, :, rank * 16:(rank + 1) * 16].clone()
+    got = exchange_halo(mine, 8)
+    lo, hi = max(0, rank * 16 - 8), min(48, (rank + 1) * 16 + 8)
+    q.put((rank, torch.equal(got, scene[:, :, lo:hi])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_halo_gloo_world3():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
