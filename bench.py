@@ -177,6 +177,7 @@ def main():
     from jspsr_amd.JSPSR import Model
     from jspsr_amd.ddp import GradReducer, broadcast_module
     from jspsr_amd.losses import MultiLoss
+    from jspsr_amd.optim import FlatAdamW
 
     _lib.load()  # fail loudly if the HIP library is missing
     np.random.seed(0)
@@ -185,7 +186,7 @@ def main():
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     broadcast_module(model)
     reducer = GradReducer(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-6, fused=True)  # configs/*.yml:71-76
+    opt = FlatAdamW(reducer, lr=1e-3, weight_decay=1e-6)  # configs/*.yml:71-76, one fused HIP launch
     criterion = MultiLoss(1.0, 1.0, 0.1)
     inputs, gt = synthetic_batch(args.batch, TILE, TILE, device, seed=1000 + rank)
 

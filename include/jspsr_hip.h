@@ -167,6 +167,25 @@ int jspsr_gate_backward_reduce(int dtype, const void* dy, const void* x, float* 
 int jspsr_gate_backward_apply(int dtype, const void* dy, const float* s, const float* davg, const float* dmax,
                               const int* amax, void* dx, int B, long long npix, int C, jspsr_stream_t stream);
 
+/* ---- the two ends of the training step ----------------------------------------------------
+ * Fused loss of the reference configs (MultiLoss, losses/loss_schemes.py:55-72; weights from
+ * configs/<name>.yml:67-70): losses[4] = {L1, L2, Grad, Total = w1*L1 + w2*L2 + wg*Grad} on fp32
+ * (B,1,H,W) tensors; Grad = L1 between normalised Sobel gradients with replicate padding
+ * (losses/loss_functions.py:171-185).  The backward writes d(Total)/d(pred) * grad_total[0]
+ * (grad_total may be NULL = 1).  workspace: jspsr_loss_workspace_bytes(), shared by both calls.
+ */
+size_t jspsr_loss_workspace_bytes(int B, int H, int W);
+int jspsr_loss_forward(const float* pred, const float* gt, float w1, float w2, float wg, float* losses,
+                       void* workspace, int B, int H, int W, jspsr_stream_t stream);
+int jspsr_loss_backward(const float* pred, const float* gt, const float* grad_total, float w1, float w2,
+                        float wg, float* grad_pred, const void* workspace, int B, int H, int W,
+                        jspsr_stream_t stream);
+
+/* One AdamW step (torch.optim.AdamW semantics: decoupled weight decay, bias correction) over a flat
+ * fp32 parameter / gradient / moment buffer of n elements (utils/common_config.py:241-291). */
+int jspsr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, jspsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,10 @@ SIGNATURES = {
     "jspsr_gate_scale": (c_i, [c_i, c_p, c_p, c_p, c_i, c_ll, c_i, c_p]),
     "jspsr_gate_backward_reduce": (c_i, [c_i, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p]),
     "jspsr_gate_backward_apply": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p]),
+    "jspsr_loss_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "jspsr_loss_forward": (c_i, [c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "jspsr_loss_backward": (c_i, [c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "jspsr_adamw_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, c_p]),
 }
 
 

@@ -1,33 +1,58 @@
 """Training loss of the reference configs (configs/*.yml:67-70): L1 + L2 + 0.1 * Sobel-L1
-(losses/loss_schemes.py:55-72, losses/loss_functions.py:171-185), evaluated on the GPU."""
+(losses/loss_schemes.py:55-72, losses/loss_functions.py:171-185) as one fused HIP forward and one
+fused HIP backward over the (B,1,H,W) prediction (jspsr_loss_forward / jspsr_loss_backward)."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
+
+from . import _lib
 
 
-def sobel_gradient(x: torch.Tensor) -> torch.Tensor:
-    """Normalised Sobel d/dx, d/dy with replicate padding: (B,C,H,W) -> (B,C,2,H,W).
-    Separable form on shifted views (smooth [1,2,1]/4 across, central difference /2 along)."""
-    xp = F.pad(x, (1, 1, 1, 1), mode="replicate")
-    sy = (xp[:, :, :-2, :] + 2 * xp[:, :, 1:-1, :] + xp[:, :, 2:, :]) * 0.25   # smoothed over rows
-    sx = (xp[:, :, :, :-2] + 2 * xp[:, :, :, 1:-1] + xp[:, :, :, 2:]) * 0.25   # smoothed over cols
-    gx = (sy[:, :, :, 2:] - sy[:, :, :, :-2]) * 0.5
-    gy = (sx[:, :, 2:, :] - sx[:, :, :-2, :]) * 0.5
-    return torch.stack((gx, gy), 2)
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, w1, w2, wg):
+        if not pred.is_cuda:
+            raise RuntimeError("jspsr_amd losses run on the GPU only (no CPU fallback)")
+        if pred.shape != gt.shape or pred.dim() != 4:
+            raise ValueError(f"loss: expected equal (B,C,H,W) shapes, got {tuple(pred.shape)} {tuple(gt.shape)}")
+        pred_c, gt_c = pred.float().contiguous(), gt.float().contiguous()
+        B, C, H, W = pred_c.shape
+        lib = _lib.load()
+        ws = torch.empty(lib.jspsr_loss_workspace_bytes(B * C, H, W), dtype=torch.uint8, device=pred.device)
+        losses = torch.empty(4, dtype=torch.float32, device=pred.device)
+        _lib.check(lib.jspsr_loss_forward(pred_c.data_ptr(), gt_c.data_ptr(), w1, w2, wg, losses.data_ptr(),
+                                          ws.data_ptr(), B * C, H, W, _stream()), "jspsr_loss_forward")
+        ctx.save_for_backward(pred_c, gt_c, ws)
+        ctx.w = (w1, w2, wg)
+        ctx.mark_non_differentiable(gt)
+        return losses
+
+    @staticmethod
+    def backward(ctx, glosses):
+        pred, gt, ws = ctx.saved_tensors
+        w1, w2, wg = ctx.w
+        B, C, H, W = pred.shape
+        g = glosses.float().contiguous()
+        gp = torch.empty_like(pred)
+        lib = _lib.load()
+        # only "Total" carries gradient (MultiLoss detaches the three components)
+        _lib.check(lib.jspsr_loss_backward(pred.data_ptr(), gt.data_ptr(), g[3:4].contiguous().data_ptr(), w1, w2, wg,
+                                           gp.data_ptr(), ws.data_ptr(), B * C, H, W, _stream()), "jspsr_loss_backward")
+        return gp, None, None, None, None
 
 
 class MultiLoss(torch.nn.Module):
-    """Returns the reference's dict {"L1","L2","Grad","Total"} (loss_schemes.py:61-72)."""
+    """Returns the reference's dict {"L1","L2","Grad","Total"} (loss_schemes.py:61-72).  Gradients flow
+    through "Total" (what the reference back-propagates, train/train_utils.py:217)."""
 
     def __init__(self, l1=1.0, l2=1.0, grad=0.1):
         super().__init__()
-        self.weights = {"L1": l1, "L2": l2, "Grad": grad}
+        self.weights = (float(l1), float(l2), float(grad))
 
     def forward(self, pred, gt):
-        d = pred - gt
-        out = {"L1": d.abs().mean(), "L2": (d * d).mean()}
-        if self.weights["Grad"]:
-            out["Grad"] = (sobel_gradient(pred) - sobel_gradient(gt)).abs().mean()
-        out["Total"] = sum(self.weights[k] * v for k, v in out.items())
-        return out
+        v = _FusedLoss.apply(pred, gt, *self.weights)
+        return {"L1": v[0].detach(), "L2": v[1].detach(), "Grad": v[2].detach(), "Total": v[3]}
