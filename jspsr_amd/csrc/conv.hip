@@ -2,6 +2,7 @@
 // Design notes: conv_igemm.h.  Entry points: include/jspsr_hip.h (jspsr_conv2d_*, jspsr_pack_weight).
 #include "conv_igemm.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -33,16 +34,14 @@ template <> struct Frag<__bf16> { using type = bf16x8; };
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
 
-struct RowInfo {  // one per tile row (m-pixel), staged in LDS
-  int b;          // image index, -1: row beyond M
-  int iy0, ix0;   // gathered pixel of tap walk index (0,0)
-  int opix;       // written pixel index (b*OH + oy)*OW + ox, -1: nothing to write
-};
 
 // UNI: Cin is a multiple of the stage depth BK, so every 16-byte chunk of a stage belongs to the
 // same tap -> the tap walk is wave-uniform (scalar registers, scalar offset of the buffer loads).
-template <typename T, int BM, int BN, int WGM, int WGN, bool UNI>
-__global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__ in,
+// NBUF: LDS staging buffers.  2 = one barrier per stage; 1 = two barriers per stage but half the LDS,
+// which doubles the resident workgroups for the narrow (N <= 64) tiles -- those layers are HBM/latency
+// bound at full resolution (input read + output write dominate), so overlap across workgroups wins.
+template <typename T, int BM, int BN, int WGM, int WGN, bool UNI, int NBUF>
+__global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const T* __restrict__ in,
                                                           const T* __restrict__ wgt,
                                                           const float* __restrict__ bias,
                                                           T* __restrict__ out, ConvGeom g) {
@@ -55,75 +54,60 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int AS_BYTES = BM * ROWB, BS_BYTES = BN * ROWB;   // one buffer
-  char* As = smem;                                  // [2][BM][ROWB]
-  char* Bs = smem + 2 * AS_BYTES;                   // [2][BN][ROWB]
-  RowInfo* rows = reinterpret_cast<RowInfo*>(smem + 2 * (AS_BYTES + BS_BYTES));  // [BM]
+  char* As = smem;                                  // [NBUF][BM][ROWB]
+  char* Bs = smem + NBUF * AS_BYTES;                // [NBUF][BN][ROWB]
 
+  // ---- tile decode ---------------------------------------------------------------------------
+  // An M-tile is a TLH x 16 block of pixels of ONE image of the m-grid (row r of the tile is pixel
+  // (ty0 + r/16, tx0 + r%16)): pixel coordinates come from shifts, no per-row table or division.
+  constexpr int TLW = 16, TLH = BM / TLW;
   const int tid = threadIdx.x;
-  const int M = g.B * g.MH * g.MW;
   const int ntn = (g.Cout + BN - 1) / BN;
-  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
-
-  if (tid < BM) {
-    RowInfo ri;
-    const int m = m0 + tid;
-    if (m < M) {
-      const int xq = m % g.MW, tq = m / g.MW, yq = tq % g.MH, b = tq / g.MH;
-      ri.b = b;
-      ri.iy0 = yq * g.iy_mul + g.iy_add;
-      ri.ix0 = xq * g.ix_mul + g.ix_add;
-      const int oy = yq * g.oy_mul + g.oy_add, ox = xq * g.ox_mul + g.ox_add;
-      ri.opix = (oy < g.OH && ox < g.OW) ? (b * g.OH + oy) * g.OW + ox : -1;
-    } else {
-      ri.b = -1;
-      ri.iy0 = ri.ix0 = 0;
-      ri.opix = -1;
-    }
-    rows[tid] = ri;
-  }
-  __syncthreads();
+  const int ttx = (g.MW + TLW - 1) / TLW, tty = (g.MH + TLH - 1) / TLH;
+  const int t = g.accumulate ? (int)blockIdx.x : xcd_contiguous(blockIdx.x, gridDim.x);  // (lab switch)
+  const int n0 = (t % ntn) * BN;
+  const int mt = t / ntn;
+  const int txi = mt % ttx, tyi = (mt / ttx) % tty, bimg = mt / (ttx * tty);
+  const int ty0 = tyi * TLH, tx0 = txi * TLW;
 
   // ---- staging plan -------------------------------------------------------------------------
-  // This thread stages 16-byte chunk `ch` of tile rows r0 + 32*i.  Everything that does not change
-  // along K is folded into per-row 32-bit byte offsets relative to a workgroup-uniform base (buffer
-  // descriptors: an out-of-range offset makes the hardware return zeros without touching memory --
-  // that is the zero padding and every other mask) and per-row validity bits over the tap walk.
+  // This thread stages 16-byte chunk `ch` of tile rows r0 + 32*i, i.e. pixels (ty0 + r0/16 + 2i,
+  // tx0 + r0%16).  Everything constant along K is folded into per-row 32-bit byte offsets relative to
+  // a workgroup-uniform base (buffer descriptors: an out-of-range offset makes the hardware return
+  // zeros without touching memory -- that is the zero padding and every other mask) and per-row
+  // validity bits over the tap walk (separable: bit ty of ymask AND bit tx of xmask).
   const int ch = tid & (NCH - 1);
   const int r0 = tid >> 3;
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  const RowInfo rfirst = rows[0];
-  const long long refpix = ((long long)(rfirst.b < 0 ? 0 : rfirst.b) * g.IH + rfirst.iy0) * g.IW + rfirst.ix0;
+  const int pix_bytes = g.in_cstride * (int)sizeof(T);
+  const int iy_ref = ty0 * g.iy_mul + g.iy_add, ix_ref = tx0 * g.ix_mul + g.ix_add;   // tap (0,0) of tile row 0
+  const long long refpix = ((long long)bimg * g.IH + iy_ref) * g.IW + ix_ref;
   const long long reach = (long long)(g.nty > 0 ? g.nty - 1 : 0) * g.IW + (g.ntx > 0 ? g.ntx - 1 : 0);
   const long long basepix = refpix - (g.sign < 0 ? reach : 0);   // lowest pixel any tap of row 0 touches
   const char* abase = reinterpret_cast<const char*>(in) + (basepix * g.in_cstride + g.in_coff) * (long long)sizeof(T);
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, 0xFFFFFF00u, 0x00020000);
   const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(wgt)), 0, 0xFFFFFF00u, 0x00020000);
-  // validity of tap (ty,tx) for a row is separable: bit ty of ymask AND bit tx of xmask
-  unsigned aoff[A_IT], ymask[A_IT], xmask[A_IT], boff[B_IT];
+  // taps q with 0 <= i0 + sign*q < extent form one contiguous run [lo, hi] of the walk
+  auto run = [&](int i0, int extent, int n) -> unsigned {
+    int lo, hi;
+    if (g.sign > 0) { lo = -i0; hi = extent - 1 - i0; } else { lo = i0 - (extent - 1); hi = i0; }
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > n - 1 ? n - 1 : hi;
+    return hi < lo ? 0u : ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+  };
+  const int sdx = r0 & (TLW - 1), sdy = r0 >> 4;                  // this thread's pixel column / first row
+  const bool colok = tx0 + sdx < g.MW;
+  const unsigned xmask = colok ? run(ix_ref + sdx * g.ix_mul, g.IW, g.ntx) : 0u;
+  unsigned aoff[A_IT], ymask[A_IT], boff[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const RowInfo ri = rows[r0 + 32 * i];
-    unsigned ym = 0, xm = 0;
-    long long rel = 0;
-    if (ri.b >= 0) {
-      // taps q with 0 <= i0 + sign*q < extent form one contiguous run [lo, hi] of the walk
-      auto run = [&](int i0, int extent, int n) -> unsigned {
-        int lo, hi;
-        if (g.sign > 0) { lo = -i0; hi = extent - 1 - i0; } else { lo = i0 - (extent - 1); hi = i0; }
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > n - 1 ? n - 1 : hi;
-        return hi < lo ? 0u : ((2u << hi) - 1u) & ~((1u << lo) - 1u);
-      };
-      ym = run(ri.iy0, g.IH, g.nty);
-      xm = run(ri.ix0, g.IW, g.ntx);
-      const long long pix = ((long long)ri.b * g.IH + ri.iy0) * g.IW + ri.ix0;
-      rel = (pix - refpix) * g.in_cstride * (long long)sizeof(T);   // >= 0: rows ascend with m
-      if (rel < 0 || rel > 0xE0000000LL) ym = 0;  // cannot happen for tensors < 3.5 GiB; stay safe
-    }
-    ymask[i] = ym;
-    xmask[i] = xm;
+    const int dy = sdy + 2 * i;                                   // rows r0 + 32*i
+    const bool rowok = colok && ty0 + dy < g.MH;
+    ymask[i] = rowok ? run(iy_ref + dy * g.iy_mul, g.IH, g.nty) : 0u;
+    // byte offset of the row's tap-(0,0) pixel from the reference pixel: >= 0 (rows ascend)
+    const long long rel = ((long long)dy * g.iy_mul * g.IW + sdx * g.ix_mul) * pix_bytes;
+    if (rel > 0xE0000000LL) ymask[i] = 0;   // cannot happen for tiles < 3.5 GiB; stay safe
     aoff[i] = (unsigned)rel + (UNI ? ch * 16u : 0u);
   }
   const int Ktot_w = g.KH * g.KW * g.Cin;  // packed weight row length
@@ -134,7 +118,6 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
     boff[i] = (K > 0 && r < BN && n < g.Cout) ? (unsigned)((size_t)n * Ktot_w * sizeof(T)) + (UNI ? ch * 16u : 0u) : OOB;
   }
   const int KT = (K + BK - 1) / BK;
-  const int pix_bytes = g.in_cstride * (int)sizeof(T);
 
   // tap walk state: of the whole stage (UNI, scalar) or of this thread's chunk
   int ci = UNI ? 0 : ch * EPC, ty = 0, tx = 0;
@@ -160,7 +143,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
       const int bdelta = (((g.ky0 + g.kstep * wy) * g.KW + (g.kx0 + g.kstep * wx)) * g.Cin + ci) * (int)sizeof(T);
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const bool ok = ((ymask[i] >> wy) & (xmask[i] >> wx) & 1u) != 0;
+        const bool ok = ((ymask[i] >> wy) & (xmask >> wx) & 1u) != 0;
         // adelta rides in the scalar offset: not part of the range check, added to the address
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? aoff[i] : OOB, adelta, 0);
         areg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
@@ -182,7 +165,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
       const unsigned bdelta = (unsigned)((((g.ky0 + g.kstep * ty) * g.KW + (g.kx0 + g.kstep * tx)) * g.Cin + ci) * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const bool ok = kok && ((ymask[i] >> ty) & (xmask[i] >> tx) & 1u);
+        const bool ok = kok && ((ymask[i] >> ty) & (xmask >> tx) & 1u);
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? aoff[i] + adelta : OOB, 0, 0);
         areg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
       }
@@ -198,7 +181,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
   char* const a_st = As + r0 * ROWB + ch * 16;   // + buf*AS_BYTES + i*32*ROWB: immediates
   char* const b_st = Bs + r0 * ROWB + ch * 16;
   auto store_stage = [&](auto SET, auto BUF) {
-    constexpr int set = decltype(SET)::value, buf = decltype(BUF)::value;
+    constexpr int set = decltype(SET)::value, buf = NBUF == 1 ? 0 : decltype(BUF)::value;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
       *reinterpret_cast<uint4*>(a_st + buf * AS_BYTES + i * 32 * ROWB) = areg[set][i];
@@ -225,7 +208,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
   const char* const b_ld = Bs + (wn * WTN + lr) * ROWB + lh * 16;
 
   auto compute = [&](auto BUF) {
-    constexpr int buf = decltype(BUF)::value;
+    constexpr int buf = NBUF == 1 ? 0 : decltype(BUF)::value;
 #pragma unroll
     for (int s = 0; s < NCH / 2; ++s) {
       frag_t a[MI], b[NI];
@@ -242,14 +225,20 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
   // one pipeline step: [issue loads of stage t+2] -> MFMAs of stage t -> [stage t+1 regs -> LDS] -> barrier.
   // Stage t lives in register set t&1 and LDS buffer t&1.  No conditionals inside a step, so hipcc
   // counts the outstanding loads exactly and waits only for the older set (vmcnt(N), never a drain).
+#ifndef CONV_ABLATE
+#define CONV_ABLATE 0   // lab builds only (tools/lab): 1 = no global loads, 2 = no MFMA/LDS reads, 3 = no LDS writes
+#endif
   auto step = [&](auto CUR, auto NXT) {
-    load_stage(CUR);            // stage t+2 -> set CUR (stage t's copy is already in LDS buffer CUR)
-    compute(CUR);               // MFMAs of stage t
-    store_stage(NXT, NXT);      // stage t+1 -> LDS buffer NXT
+    if (CONV_ABLATE != 1 && CONV_ABLATE != 5) load_stage(CUR);   // stage t+2 -> set CUR (stage t's copy is already in LDS buffer CUR)
+    if (CONV_ABLATE != 2) compute(CUR);      // MFMAs of stage t
+    if (NBUF == 1) __syncthreads();          // single buffer: everyone is done reading stage t
+    if (CONV_ABLATE != 3) store_stage(NXT, NXT);  // stage t+1 -> LDS buffer NXT
     __syncthreads();
   };
-  load_stage(S0{});
-  load_stage(S1{});
+  if (CONV_ABLATE != 5) {
+    load_stage(S0{});
+    load_stage(S1{});
+  }
   store_stage(S0{}, S0{});
   __syncthreads();
   int kt = 0;
@@ -259,7 +248,16 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
   }
   if (kt < KT) step(S0{}, S1{});
 
-  // epilogue: C row = (e&3) + 8*(e>>2) + 4*lh, C col = lr.  One pointer per output row.
+  // ---- epilogue ------------------------------------------------------------------------------
+  // C row = (e&3) + 8*(e>>2) + 4*lh, C col = lr: a lane holds ONE channel of 16 rows, so direct stores
+  // would be 2-/4-byte scatters.  The tile is transposed through LDS (the staging buffers are free
+  // now) and written with 16-byte stores: every output row leaves as one contiguous run.
+  // written pixel of tile row `row`, -1 if the row is outside the m-grid or the written raster
+  auto out_pixel = [&](int row) -> long long {
+    const int y = ty0 + (row >> 4), x = tx0 + (row & (TLW - 1));
+    const int oy = y * g.oy_mul + g.oy_add, ox = x * g.ox_mul + g.ox_add;
+    return (y < g.MH && x < g.MW && oy < g.OH && ox < g.OW) ? ((long long)bimg * g.OH + oy) * g.OW + ox : -1;
+  };
   float bv[NI];
   int ncol[NI];
 #pragma unroll
@@ -267,55 +265,98 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const T* __restrict__
     ncol[ni] = n0 + wn * WTN + ni * 32 + lr;
     bv[ni] = (bias && ncol[ni] < g.Cout) ? bias[ncol[ni]] : 0.f;
   }
+  constexpr int OPITCH = BN * (int)sizeof(T) + 16;       // bytes per staged output row (+16: bank spread)
+  // the launcher sizes dynamic LDS as max(staging, BM * OPITCH)
+  if (NBUF == 1) __syncthreads();
+  char* Os = smem;
+  const bool vec_ok = (g.Cout - n0 >= BN) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
+                      (((g.out_coff + n0) * (int)sizeof(T)) % 16 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+  if (vec_ok) {
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      const int opix = rows[row].opix;
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          float v = acc[mi][ni][e] + bv[ni];
+          if (g.relu) v = fmaxf(v, 0.f);
+          *reinterpret_cast<T*>(Os + row * OPITCH + (wn * WTN + ni * 32 + lr) * (int)sizeof(T)) = (T)v;
+        }
+      }
+    __syncthreads();
+    constexpr int CPRO = BN * (int)sizeof(T) / 16;       // 16-byte chunks per output row
+    char* const obase = reinterpret_cast<char*>(out + g.out_coff + n0);
+    for (int i = tid; i < BM * CPRO; i += NT) {
+      const int row = i / CPRO, c16 = i % CPRO;
+      const long long opix = out_pixel(row);
       if (opix < 0) continue;
-      T* orow = out + (size_t)opix * g.out_cstride + g.out_coff;
+      const uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
+      if (CONV_ABLATE == 4 && v.x != 0x12345678u) continue;   // lab: no output stores
+      *reinterpret_cast<uint4*>(obase + opix * g.out_cstride * (long long)sizeof(T) + c16 * 16) = v;
+    }
+  } else {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (ncol[ni] >= g.Cout) continue;
-        float v = acc[mi][ni][e] + bv[ni];
-        if (g.relu) v = fmaxf(v, 0.f);
-        orow[ncol[ni]] = (T)v;
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const long long opix = out_pixel(row);
+        if (opix < 0) continue;
+        T* orow = out + opix * g.out_cstride + g.out_coff;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (ncol[ni] >= g.Cout) continue;
+          float v = acc[mi][ni][e] + bv[ni];
+          if (g.relu) v = fmaxf(v, 0.f);
+          orow[ncol[ni]] = (T)v;
+        }
       }
     }
   }
 }
 
-template <typename T, int BM, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN, int NBUF>
 int launch_cfg(const void* in, const void* wgt, const float* bias, void* out, const ConvGeom& g, hipStream_t s) {
-  const long long M = (long long)g.B * g.MH * g.MW;
-  if (M <= 0) return JSPSR_OK;
-  const long long nblk = ((M + BM - 1) / BM) * ((g.Cout + BN - 1) / BN);
+  if ((long long)g.B * g.MH * g.MW <= 0) return JSPSR_OK;
+  constexpr int TLW = 16, TLH = BM / TLW;
+  const long long nblk = (long long)g.B * ((g.MH + TLH - 1) / TLH) * ((g.MW + TLW - 1) / TLW) * ((g.Cout + BN - 1) / BN);
   if (nblk > 0x7fffffffLL) return fail(JSPSR_EINVAL, "conv: grid too large");
-  const size_t lds = 2 * (BM + BN) * ROWB + BM * sizeof(RowInfo);
+  const size_t lds_stage = NBUF * (BM + BN) * ROWB, lds_out = (size_t)BM * (BN * sizeof(T) + 16);
+  const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
   constexpr int BK = NCH * Elem<T>::EPC;
   static bool attr_set = false;  // > 64 KiB dynamic LDS needs the opt-in once per kernel
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BM, BN, WGM, WGN, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BM, BN, WGM, WGN, true, NBUF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BM, BN, WGM, WGN, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, BM, BN, WGM, WGN, false, NBUF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   if (g.Cin % BK == 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true>), dim3((unsigned)nblk), dim3(NT), lds, s,
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true, NBUF>), dim3((unsigned)nblk), dim3(NT), lds, s,
                        static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), g);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false>), dim3((unsigned)nblk), dim3(NT), lds, s,
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false, NBUF>), dim3((unsigned)nblk), dim3(NT), lds, s,
                        static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), g);
   return check_launch("conv_igemm");
 }
 
 template <typename T>
 int launch(const void* in, const void* wgt, const float* bias, void* out, const ConvGeom& g, hipStream_t s) {
-  if (g.Cout > 64) return launch_cfg<T, 128, 128, 2, 2>(in, wgt, bias, out, g, s);
-  if (g.Cout > 32) return launch_cfg<T, 128, 64, 2, 2>(in, wgt, bias, out, g, s);
-  return launch_cfg<T, 128, 32, 4, 1>(in, wgt, bias, out, g, s);
+  // narrow tiles: single LDS buffer (4 resident workgroups per CU) while K is short -- the layer is then
+  // HBM/latency bound and overlap across workgroups wins; double buffer for long K (measured crossover
+  // between K = 576 and K = 2304 on MI355X).  JSPSR_CONV_NBUF overrides for experiments.
+  static const int nbuf_env = [] { const char* e = getenv("JSPSR_CONV_NBUF"); return e ? atoi(e) : 0; }();
+  const int nbuf_narrow = nbuf_env ? nbuf_env : ((long long)g.nty * g.ntx * g.Cin <= 1152 ? 1 : 2);
+  if (g.Cout > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(in, wgt, bias, out, g, s);
+  if (nbuf_narrow == 2) {
+    if (g.Cout > 32) return launch_cfg<T, 128, 64, 2, 2, 2>(in, wgt, bias, out, g, s);
+    return launch_cfg<T, 128, 32, 4, 1, 2>(in, wgt, bias, out, g, s);
+  }
+  if (g.Cout > 32) return launch_cfg<T, 128, 64, 2, 2, 1>(in, wgt, bias, out, g, s);
+  return launch_cfg<T, 128, 32, 4, 1, 1>(in, wgt, bias, out, g, s);
 }
 
 int check_common(int dtype, const void* a, const void* w, const void* o, int cin, int cs_in, int co_in,
@@ -385,6 +426,7 @@ extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack
   g.iy_mul = stride; g.iy_add = -pad; g.ix_mul = stride; g.ix_add = -pad; g.sign = 1;
   g.nty = KH; g.ntx = KW; g.ky0 = 0; g.kx0 = 0; g.kstep = 1; g.KH = KH; g.KW = KW;
   g.oy_mul = 1; g.oy_add = 0; g.ox_mul = 1; g.ox_add = 0; g.relu = relu;
+  g.accumulate = getenv("JSPSR_CONV_NOXCD") ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == JSPSR_F32 ? launch<float>(in, wpack, bias, out, g, s) : launch<__bf16>(in, wpack, bias, out, g, s);
 }

@@ -257,23 +257,36 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
 }
 
 // dW[r][c][ky][kx] (+)= sum_z ws[z][r][(ky*KW+kx)*Cx + c],  r < R, c < C  (fixed summation order).
-// Threads walk the slab layout (coalesced reads of every slab); the scattered 4-byte writes into the
-// (R, C, KH, KW) master layout are the small side.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int R, int C, int KH,
-                                    int KW, int Cg, int Cx, int splits, int accumulate) {
+// A (32 x 8)-thread workgroup owns 32 consecutive slab elements (128-byte coalesced reads of every
+// slab); its 8 z-lanes each sum every 8th slab, then fold in a fixed order.  The scattered 4-byte
+// writes into the (R, C, KH, KW) master layout are the small side.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int R,
+                                                          int C, int KH, int KW, int Cg, int Cx, int splits,
+                                                          int accumulate) {
+  __shared__ float red[8][32];
   const int Ktot = KH * KW * Cx;
   const long long total = (long long)R * Ktot;
   const size_t slab = (size_t)Cg * Ktot;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / Ktot), k = (int)(idx % Ktot);
-    const int tap = k / Cx, c = k % Cx;
-    if (c >= C) continue;
-    const size_t src = (size_t)r * Ktot + k;
+  const int ex = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+    const long long idx = base + ex;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[z * slab + src];
-    const size_t dst = ((size_t)r * C + c) * (KH * KW) + tap;
-    dW[dst] = accumulate ? dW[dst] + s : s;
+    if (idx < total)
+      for (int z = zl; z < splits; z += 8) s += ws[z * slab + idx];   // slab rows of G channels < R are a prefix
+    red[zl][ex] = s;
+    __syncthreads();
+    if (zl == 0 && idx < total) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += red[q][ex];
+      const int r = (int)(idx / Ktot), k = (int)(idx % Ktot);
+      const int tap = k / Cx, c = k % Cx;
+      if (c < C) {
+        const size_t dst = ((size_t)r * C + c) * (KH * KW) + tap;
+        dW[dst] = accumulate ? dW[dst] + t : t;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -329,7 +342,7 @@ int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradG
   else e = launch_w<T, 32, 1, 4>(G, X, ws, g, p.splits, s);
   if (e) return e;
   const long long total = (long long)R * g.Ktot;
-  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  const int blocks = (int)((total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dW, R, C, g.KH, g.KW, g.Cg, g.Cx,
                      p.splits, accumulate);
   return check_launch("conv2d_wgrad_reduce");

@@ -17,6 +17,10 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
     (8, 64, 64, 1536, 256, 3, 1),
     (8, 512, 512, 256, 64, 3, 1),
     (8, 512, 512, 192, 128, 3, 2),
+    (8, 512, 512, 64, 64, 1, 1),     # 8: K sweep at N = 64 (fixed per-tile cost vs per-stage cost)
+    (8, 512, 512, 64, 64, 5, 1),     # 9
+    (8, 512, 512, 128, 128, 1, 1),   # 10
+    (8, 512, 512, 128, 128, 5, 1),   # 11
 ]
 
 
