@@ -317,6 +317,270 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Patch variant for unit-stride tap walks (forward stride-1 convs, every data-gradient /
+// transposed-conv phase) with Cin a multiple of the stage depth.  The implicit-GEMM kernel above
+// re-stages the A tile once per TAP (9 x for a 3x3); here the (TLH+nty-1) x (16+ntx-1) input patch
+// of the current 64-/32-channel chunk is staged in LDS ONCE and every tap reads its A operand from
+// it at a shifted row, so global->LDS traffic for A drops from ntaps x to ~1.4 x.  Only the weight
+// tile still streams per tap (two-deep register prefetch).  The next chunk's patch is prefetched
+// into registers at the first tap of the current chunk and written at its last.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+                                                          const float* __restrict__ bias, T* __restrict__ out,
+                                                          ConvGeom g) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int BM = 128, TLW = 16, TLH = BM / TLW;
+  constexpr int EPC = Elem<T>::EPC, BK = NCH * EPC;
+  constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
+  constexpr int B_IT = (BN * NCH + NT - 1) / NT;
+  constexpr int P_IT = 6;                    // patch chunks per thread: (8+2)*(16+2) pixels * 8 chunks <= 6 * 256
+  constexpr int MAXPIX = P_IT * NT / NCH;    // 192 patch pixels
+  constexpr int BS_BYTES = BN * ROWB;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  using frag_t = typename Frag<T>::type;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ps = smem;                          // [MAXPIX][ROWB]   input patch of the current channel chunk
+  char* Bs = smem + MAXPIX * ROWB;          // [2][BN][ROWB]    weight tile of the current / next tap
+
+  const int tid = threadIdx.x;
+  const int ntn = (g.Cout + BN - 1) / BN;
+  const int ttx = (g.MW + TLW - 1) / TLW, tty = (g.MH + TLH - 1) / TLH;
+  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int n0 = (t % ntn) * BN;
+  const int mt = t / ntn;
+  const int txi = mt % ttx, tyi = (mt / ttx) % tty, bimg = mt / (ttx * tty);
+  const int ty0 = tyi * TLH, tx0 = txi * TLW;
+
+  const int PW = TLW + g.ntx - 1, PH = TLH + g.nty - 1, npix = PW * PH;
+  const int pix_bytes = g.in_cstride * (int)sizeof(T);
+  // patch origin in the gathered raster (reversed walk: the patch starts nty-1 / ntx-1 pixels earlier)
+  const int oy0 = ty0 + g.iy_add - (g.sign < 0 ? g.nty - 1 : 0);
+  const int ox0 = tx0 + g.ix_add - (g.sign < 0 ? g.ntx - 1 : 0);
+  const long long opix0 = ((long long)bimg * g.IH + oy0) * g.IW + ox0;    // may lie outside the raster
+  const char* abase = reinterpret_cast<const char*>(in) + (opix0 * g.in_cstride + g.in_coff) * (long long)sizeof(T);
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, 0xFFFFFF00u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(wgt)), 0, 0xFFFFFF00u, 0x00020000);
+
+  // patch staging plan: this thread owns 16-byte chunk `ch` of patch pixels p0 + 32*i
+  const int ch = tid & (NCH - 1);
+  unsigned poff[P_IT];       // global byte offset of the pixel (+ chunk) from the patch origin, OOB if padding
+  int plds[P_IT];            // LDS byte offset, -1 if this slot is beyond the patch
+  {
+    int pp = tid >> 3;
+    int py = pp / PW, px = pp - py * PW;
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const bool inpatch = pp < npix;
+      const int iy = oy0 + py, ix = ox0 + px;
+      const bool ok = inpatch && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+      poff[i] = ok ? (unsigned)((py * g.IW + px) * pix_bytes) + ch * 16u : OOB;
+      plds[i] = inpatch ? pp * ROWB + ch * 16 : -1;
+      pp += NT / NCH;
+      px += NT / NCH;
+      while (px >= PW) { px -= PW; ++py; }
+    }
+  }
+  const int r0 = tid >> 3;
+  const int Ktot_w = g.KH * g.KW * g.Cin;
+  const int ntaps = g.nty * g.ntx, nchunks = g.Cin / BK;
+  const int KT = ntaps * nchunks;
+  unsigned boff[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int r = r0 + 32 * i, n = n0 + r;
+    boff[i] = (KT > 0 && r < BN && n < g.Cout) ? (unsigned)((size_t)n * Ktot_w * sizeof(T)) + ch * 16u : OOB;
+  }
+
+  uint4 preg[P_IT], breg[2][B_IT];
+  auto load_patch = [&](int chunk) {
+    const int soff = chunk * BK * (int)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, poff[i], soff, 0);
+      preg[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i)
+      if (plds[i] >= 0) *reinterpret_cast<uint4*>(Ps + plds[i]) = preg[i];
+  };
+  // weight-tile walk (chunk-major, taps inner): state of the NEXT stage to load
+  int lty = 0, ltx = 0, lchunk = 0;
+  auto load_b = [&](auto SET) {
+    constexpr int set = decltype(SET)::value;
+    const bool past = lchunk >= nchunks;       // past the end: re-read stage 0 (staged, never multiplied)
+    const int wy = past ? 0 : lty, wx = past ? 0 : ltx, wc = past ? 0 : lchunk;
+    const int bdelta = (((g.ky0 + g.kstep * wy) * g.KW + (g.kx0 + g.kstep * wx)) * g.Cin + wc * BK) * (int)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(brsrc, boff[i], bdelta, 0);
+      breg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    if (++ltx == g.ntx) { ltx = 0; if (++lty == g.nty) { lty = 0; ++lchunk; } }
+  };
+  char* const b_st = Bs + r0 * ROWB + ch * 16;
+  auto store_b = [&](auto SET, auto BUF) {
+    constexpr int set = decltype(SET)::value, buf = decltype(BUF)::value;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      if (B_IT * 32 <= BN || r0 + 32 * i < BN)
+        *reinterpret_cast<uint4*>(b_st + buf * BS_BYTES + i * 32 * ROWB) = breg[set][i];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int lr = lane & 31, lh = lane >> 5;
+  // A operand: MFMA row lr of block mi is tile pixel (dy, dx) = ((wm*WTM + mi*32 + lr) / 16, lr % 16);
+  // at tap (ty,tx) it reads patch pixel (dy + oy(ty), dx + ox(tx))
+  int a_ld[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * WTM + mi * 32 + lr;
+    a_ld[mi] = ((row >> 4) * PW + (row & (TLW - 1))) * ROWB + lh * 16;
+  }
+  const char* const b_ld = Bs + (wn * WTN + lr) * ROWB + lh * 16;
+
+  int cty = 0, ctx = 0, cchunk = 0;   // stage being computed
+  auto compute = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+    const int oy = g.sign > 0 ? cty : g.nty - 1 - cty, ox = g.sign > 0 ? ctx : g.ntx - 1 - ctx;
+    const int tapoff = (oy * PW + ox) * ROWB;
+#pragma unroll
+    for (int s = 0; s < NCH / 2; ++s) {
+      frag_t a[MI], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag_t*>(Ps + a_ld[mi] + tapoff + s * 32);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const frag_t*>(b_ld + buf * BS_BYTES + ni * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma_chunk(acc[mi][ni], a[mi], b[ni]);
+    }
+  };
+  auto step = [&](auto CUR, auto NXT) {
+    load_b(CUR);                                               // weights of stage s+2
+    const bool first_tap = (cty == 0 && ctx == 0), more = cchunk + 1 < nchunks;
+    if (first_tap && more) load_patch(cchunk + 1);             // next chunk's patch: lands during this chunk's taps
+    compute(CUR);
+    const bool last_tap = (cty == g.nty - 1 && ctx == g.ntx - 1);
+    if (last_tap && more) {
+      __syncthreads();                                         // everyone is done with this chunk's patch
+      store_patch();
+    }
+    store_b(NXT, NXT);
+    __syncthreads();
+    if (++ctx == g.ntx) { ctx = 0; if (++cty == g.nty) { cty = 0; ++cchunk; } }
+  };
+  if (KT > 0) {
+    load_patch(0);
+    load_b(S0{});
+    load_b(S1{});
+    store_patch();
+    store_b(S0{}, S0{});
+  }
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < KT; kt += 2) {
+    step(S0{}, S1{});
+    step(S1{}, S0{});
+  }
+  if (kt < KT) step(S0{}, S1{});
+
+  // ---- epilogue (as above): transpose through LDS, 16-byte stores ----------------------------
+  auto out_pixel = [&](int row) -> long long {
+    const int y = ty0 + (row >> 4), x = tx0 + (row & (TLW - 1));
+    const int oy = y * g.oy_mul + g.oy_add, ox = x * g.ox_mul + g.ox_add;
+    return (y < g.MH && x < g.MW && oy < g.OH && ox < g.OW) ? ((long long)bimg * g.OH + oy) * g.OW + ox : -1;
+  };
+  float bv[NI];
+  int ncol[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    ncol[ni] = n0 + wn * WTN + ni * 32 + lr;
+    bv[ni] = (bias && ncol[ni] < g.Cout) ? bias[ncol[ni]] : 0.f;
+  }
+  constexpr int OPITCH = BN * (int)sizeof(T) + 16;
+  char* Os = smem;
+  const bool vec_ok = (g.Cout - n0 >= BN) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
+                      (((g.out_coff + n0) * (int)sizeof(T)) % 16 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+  if (vec_ok) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          float v = acc[mi][ni][e] + bv[ni];
+          if (g.relu) v = fmaxf(v, 0.f);
+          *reinterpret_cast<T*>(Os + row * OPITCH + (wn * WTN + ni * 32 + lr) * (int)sizeof(T)) = (T)v;
+        }
+      }
+    __syncthreads();
+    constexpr int CPRO = BN * (int)sizeof(T) / 16;
+    char* const obase = reinterpret_cast<char*>(out + g.out_coff + n0);
+    for (int i = tid; i < BM * CPRO; i += NT) {
+      const int row = i / CPRO, c16 = i % CPRO;
+      const long long opix = out_pixel(row);
+      if (opix < 0) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
+      *reinterpret_cast<uint4*>(obase + opix * g.out_cstride * (long long)sizeof(T) + c16 * 16) = v;
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const long long opix = out_pixel(row);
+        if (opix < 0) continue;
+        T* orow = out + opix * g.out_cstride + g.out_coff;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (ncol[ni] >= g.Cout) continue;
+          float v = acc[mi][ni][e] + bv[ni];
+          if (g.relu) v = fmaxf(v, 0.f);
+          orow[ncol[ni]] = (T)v;
+        }
+      }
+  }
+}
+
+template <typename T, int BN, int WGM, int WGN>
+int launch_patch(const void* in, const void* wgt, const float* bias, void* out, const ConvGeom& g, hipStream_t s) {
+  constexpr int BM = 128, TLW = 16, TLH = BM / TLW, MAXPIX = 6 * NT / NCH;
+  const long long nblk = (long long)g.B * ((g.MH + TLH - 1) / TLH) * ((g.MW + TLW - 1) / TLW) * ((g.Cout + BN - 1) / BN);
+  if (nblk > 0x7fffffffLL) return fail(JSPSR_EINVAL, "conv: grid too large");
+  const size_t lds_stage = (size_t)MAXPIX * ROWB + 2 * BN * ROWB, lds_out = (size_t)BM * (BN * sizeof(T) + 16);
+  const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
+  auto kern = conv_patch_kernel<T, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, s, static_cast<const T*>(in), static_cast<const T*>(wgt),
+                     bias, static_cast<T*>(out), g);
+  return check_launch("conv_patch");
+}
+
 template <typename T, int BM, int BN, int WGM, int WGN, int NBUF>
 int launch_cfg(const void* in, const void* wgt, const float* bias, void* out, const ConvGeom& g, hipStream_t s) {
   if ((long long)g.B * g.MH * g.MW <= 0) return JSPSR_OK;
@@ -348,6 +612,15 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, const 
   // narrow tiles: single LDS buffer (4 resident workgroups per CU) while K is short -- the layer is then
   // HBM/latency bound and overlap across workgroups wins; double buffer for long K (measured crossover
   // between K = 576 and K = 2304 on MI355X).  JSPSR_CONV_NBUF overrides for experiments.
+  // unit-stride tap walk, <= 3x3 taps, Cin a multiple of the stage depth: stage the input patch once
+  static const int no_patch = [] { const char* e = getenv("JSPSR_CONV_NOPATCH"); return e ? atoi(e) : 0; }();
+  constexpr int BKT = NCH * Elem<T>::EPC;
+  if (!no_patch && g.iy_mul == 1 && g.ix_mul == 1 && g.nty >= 1 && g.ntx >= 1 && g.nty <= 3 && g.ntx <= 3 &&
+      g.nty * g.ntx > 1 && g.Cin % BKT == 0 && (long long)(g.IW + 20) * 12 * g.in_cstride * (long long)sizeof(T) < 0xE0000000LL) {
+    if (g.Cout > 64) return launch_patch<T, 128, 2, 2>(in, wgt, bias, out, g, s);
+    if (g.Cout > 32) return launch_patch<T, 64, 2, 2>(in, wgt, bias, out, g, s);
+    return launch_patch<T, 32, 4, 1>(in, wgt, bias, out, g, s);
+  }
   static const int nbuf_env = [] { const char* e = getenv("JSPSR_CONV_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf_narrow = nbuf_env ? nbuf_env : ((long long)g.nty * g.ntx * g.Cin <= 1152 ? 1 : 2);
   if (g.Cout > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(in, wgt, bias, out, g, s);

@@ -138,7 +138,9 @@ def gen_model(ref_jspsr, path, in_channels, nf, B, H, W, seed, training):
     model.train(training)
     inputs, gt = R.synthetic_batch(B, H, W, "mask" in in_channels, seed=seed + 1, dtype=torch.float64)
     pred = model(*inputs)
-    loss = (pred - gt).abs().mean() + ((pred - gt) ** 2).mean()  # L1 + L2 (torch built-ins)
+    loss = (pred - gt).abs().mean() + ((pred - gt) ** 2).mean()  # L1 + L2 (torch built-ins): value only
+    # gradients are taken through a fixed linear probe (R.probe_gradient): see its docstring
+    loss_smooth = (pred * R.probe_gradient(pred.shape, seed + 2)).mean()
     store = {
         "pred": pred.detach().numpy(), "loss": np.float64(loss.item()),
         "seed": np.int64(seed), "nf": np.int64(nf), "BHW": np.array([B, H, W]),
@@ -147,7 +149,7 @@ def gen_model(ref_jspsr, path, in_channels, nf, B, H, W, seed, training):
         "input_abs_sum": np.float64(sum(t.abs().sum().item() for t in inputs) + gt.abs().sum().item()),
     }
     if training:
-        loss.backward()
+        loss_smooth.backward()
         names, norms = [], []
         for k, p in model.named_parameters():
             names.append(k)
@@ -203,7 +205,7 @@ def gen_lrru(path, B, H, W, seed, training):
              "BHW": np.array([B, H, W]), "training": np.bool_(training),
              "param_abs_sum": np.float64(sum(v.double().abs().sum().item() for v in sd.values()))}
     if training:
-        loss.backward()
+        (pred * R.probe_gradient(pred.shape, seed + 2)).mean().backward()
         _store_grads(model, store, ("weight_offset3.conv_weight.weight", "Post_process.w", "weight_offset3.convf1.conv.0.weight"))
     np.savez(path, **store)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
@@ -227,7 +229,7 @@ def gen_edsr(path, B, H, W, seed, training):
              "BHW": np.array([B, H, W]), "training": np.bool_(training),
              "param_abs_sum": np.float64(sum(v.double().abs().sum().item() for v in sd.values()))}
     if training:
-        loss.backward()
+        (pred * R.probe_gradient(pred.shape, seed + 2)).mean().backward()
         _store_grads(model, store, ("entry.weight", "generator.conv_weight.0.weight", "post_layer.w"))
     np.savez(path, **store)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -659,3 +659,11 @@ def edsr_forward(sd: SD, x: torch.Tensor, training: bool, n_resblocks=16, res_sc
     h = h + res_scale * xs
     weight, offset = generator(c, dem, h)
     return propagate(dem, weight, offset, sd["post_layer.w"], sd["post_layer.b"], 1.0)
+
+
+def probe_gradient(shape, seed: int, dtype=torch.float64) -> torch.Tensor:
+    """Fixed upstream gradient for backward-pass fixtures: d(loss)/d(pred) = G / numel with a seeded random
+    G.  A data loss would make d(loss)/d(pred) = f(pred - gt); with |pred - gt| ~ 1e-3 an fp32 forward error of
+    5e-6 turns into a 0.5 % relative error of every gradient, which says nothing about the backward kernels."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float64).to(dtype)

@@ -36,6 +36,11 @@ CASES = [
     (1, 20, 28, 16, 32, 5, 1, 2),       # stem, 15 -> 16
     (1, 8, 8, 1536, 256, 3, 1, 1),      # deep K
     (1, 17, 19, 8, 200, 3, 1, 1),       # N not a tile multiple
+    (2, 12, 20, 96, 32, 3, 1, 1),       # several channel chunks, raster smaller than / ragged against the 8x16 tile
+    (2, 6, 10, 256, 64, 3, 1, 1),
+    (2, 24, 40, 64, 32, 3, 1, 1),
+    (2, 48, 80, 192, 16, 3, 1, 1),
+    (1, 6, 10, 128, 128, 3, 2, 1),
 ]
 
 
