@@ -61,8 +61,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
   char* Xs = smem + 2 * GS_BYTES;     // [2][BKM][XP]
 
   const int tid = threadIdx.x;
-  const int co0 = blockIdx.x * BMC, n0 = blockIdx.y * BNC;
-  const long long m_begin = (long long)blockIdx.z * g.m_per_split;
+  // 1-D grid, numbered so that one XCD (private L2) gets a contiguous run of (slice, column group, row
+  // tile) triples: the column groups (taps) of one pixel slice share their G rows and overlapping X rows
+  const int gx = (g.Cg + BMC - 1) / BMC, gy = (g.Ktot + BNC - 1) / BNC;
+  const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int bx = lin % gx, by = (lin / gx) % gy, bz = lin / (gx * gy);
+  const int co0 = bx * BMC, n0 = by * BNC;
+  const long long m_begin = (long long)bz * g.m_per_split;
   const long long m_end = (m_begin + g.m_per_split < g.M) ? m_begin + g.m_per_split : g.M;
   const int KT = (int)((m_end - m_begin + BKM - 1) / BKM);
 
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
   }
   if (kt < KT) step(S0{}, S1{});
 
-  float* slab = ws + (size_t)blockIdx.z * g.Cg * g.Ktot;
+  float* slab = ws + (size_t)bz * g.Cg * g.Ktot;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int k = n0 + wn * WTN + ni * 32 + lr;
@@ -321,8 +326,8 @@ int launch_w(const void* G, const void* X, float* ws, const WgradGeom& g, int sp
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid((g.Cg + BMC - 1) / BMC, (g.Ktot + BNC - 1) / BNC, splits);
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, static_cast<const T*>(G), static_cast<const T*>(X), ws, g);
+  const long long nblk = (long long)((g.Cg + BMC - 1) / BMC) * ((g.Ktot + BNC - 1) / BNC) * splits;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, s, static_cast<const T*>(G), static_cast<const T*>(X), ws, g);
   return check_launch("conv2d_wgrad");
 }
 
