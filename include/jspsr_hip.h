@@ -139,11 +139,12 @@ int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, const void*
                      int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
                      void* workspace, jspsr_stream_t stream);
 
-/* Backward of the above.  dy is the gradient w.r.t. y; y is only read when relu != 0 (mask y > 0).
+/* Backward of the above.  dy is the gradient w.r.t. y.  relu: 0 = none; 1 = mask from the saved output
+ * (y > 0); 2 = mask recomputed from x as gamma*xhat + beta > 0 (valid without a residual; y is not read).
  * dx (dense, pitch C) = grad w.r.t. x; dres (dense, may be NULL) = grad w.r.t. res;
  * dgamma, dbeta [C] overwritten. */
 int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
-                      const void* x, int x_cs, int x_coff, const float* gamma, const float* save_mean,
+                      const void* x, int x_cs, int x_coff, const float* gamma, const float* beta, const float* save_mean,
                       const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
                       float* dgamma, float* dbeta, long long npix, int C, void* workspace,
                       jspsr_stream_t stream);

@@ -12,6 +12,8 @@
 // -> bit-reproducible statistics, no atomics.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 using namespace jspsr;
@@ -135,7 +137,8 @@ RedGeom make_red(long long npix, int nseg, int C, int vec) {
   RedGeom g;
   g.npix = npix; g.nseg = nseg; g.C = C;
   const int gy = (C / vec + TX - 1) / TX;
-  long long want = 2048 / ((long long)gy * nseg);
+  static const int target = [] { const char* e = getenv("JSPSR_RED_BLOCKS"); return e ? atoi(e) : 1024; }();   // 768-1024 measured best on MI355X (256 CUs x 3-4)
+  long long want = target / ((long long)gy * nseg);
   if (want < 1) want = 1;
   long long chunks = (npix + 63) / 64;  // >= 64 pixels per chunk
   if (chunks > want) chunks = want;
@@ -267,19 +270,25 @@ __global__ __launch_bounds__(TX * TY) void bn_bwd_reduce_kernel(const T* __restr
                                                                const T* __restrict__ y, int y_cs, int y_coff,
                                                                const T* __restrict__ x, int x_cs, int x_coff,
                                                                const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd, int relu, RedGeom g,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int relu, RedGeom g,
                                                                float* __restrict__ partial) {
   constexpr int N = V<T>::N;
+  // relu == 1: mask from the saved output y;  relu == 2 (no residual): mask recomputed from x,
+  // [gamma*xhat + beta > 0], which saves reading y
   reduce_pixels<T, 2>(g, partial, [&](long long pix, int c, float (&acc)[2][N]) {
     float d[N], xv[N], yv[N];
     load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
     load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, xv);
-    if (relu) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
+    if (relu == 1) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const float dz = (relu && !(yv[i] > 0.f)) ? 0.f : d[i];
+      const float xhat = (xv[i] - mean[c + i]) * invstd[c + i];
+      const bool off = relu == 1 ? !(yv[i] > 0.f) : (relu == 2 ? !(gamma[c + i] * xhat + beta[c + i] > 0.f) : false);
+      const float dz = off ? 0.f : d[i];
       acc[0][i] += dz;
-      acc[1][i] += dz * (xv[i] - mean[c + i]) * invstd[c + i];
+      acc[1][i] += dz * xhat;
     }
   });
 }
@@ -308,26 +317,29 @@ __global__ __launch_bounds__(TX * TY) void bn_bwd_apply_kernel(const T* __restri
                                                               const T* __restrict__ y, int y_cs, int y_coff,
                                                               const T* __restrict__ x, int x_cs, int x_coff,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ coef, int relu,
                                                               T* __restrict__ dx, T* __restrict__ dres, RedGeom g) {
   constexpr int N = V<T>::N;
   const int C = g.C;
-  float mu[N], is[N], k0[N], ka[N], kb[N];
+  float mu[N], is[N], k0[N], ka[N], kb[N], ga[N], be[N];
   const int c0 = lane_map<N>(g).c;
   if (c0 < C) {
     load_param<N>(mean + c0, mu); load_param<N>(invstd + c0, is);
     load_param<N>(coef + c0, k0); load_param<N>(coef + C + c0, ka); load_param<N>(coef + 2 * C + c0, kb);
+    if (relu == 2) { load_param<N>(gamma + c0, ga); load_param<N>(beta + c0, be); }
   }
   for_pixels<T>(g, [&](int, long long, long long pix, int c) {
     float d[N], xv[N], yv[N], o[N];
     load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
     load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, xv);
-    if (relu) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
+    if (relu == 1) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float dz = (relu && !(yv[k] > 0.f)) ? 0.f : d[k];
-      d[k] = dz;
       const float xhat = (xv[k] - mu[k]) * is[k];
+      const bool off = relu == 1 ? !(yv[k] > 0.f) : (relu == 2 ? !(ga[k] * xhat + be[k] > 0.f) : false);
+      const float dz = off ? 0.f : d[k];
+      d[k] = dz;
       o[k] = k0[k] * (dz - ka[k] - xhat * kb[k]);
     }
     store_vec<T>(dx + (size_t)pix * C + c, o);
@@ -558,15 +570,16 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
 }
 
 extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
-                                 const void* x, int x_cs, int x_coff, const float* gamma, const float* save_mean,
+                                 const void* x, int x_cs, int x_coff, const float* gamma, const float* beta, const float* save_mean,
                                  const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
                                  float* dgamma, float* dbeta, long long npix, int C, void* workspace,
                                  jspsr_stream_t stream) {
   if (int e = check_c(dtype, C, "bn_backward")) return e;
-  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || npix <= 0 || (relu && !y))
-    return fail(JSPSR_EINVAL, "bn_backward: null pointer or empty tensor");
+  if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || npix <= 0 ||
+      (relu == 1 && !y) || (relu == 2 && !beta) || relu < 0 || relu > 2)
+    return fail(JSPSR_EINVAL, "bn_backward: null pointer, empty tensor or bad relu mode");
   const int vec = dtype == JSPSR_F32 ? 4 : 8;
-  if (dy_cs % vec || dy_coff % vec || x_cs % vec || x_coff % vec || (relu && (y_cs % vec || y_coff % vec)))
+  if (dy_cs % vec || dy_coff % vec || x_cs % vec || x_coff % vec || (relu == 1 && (y_cs % vec || y_coff % vec)))
     return fail(JSPSR_EINVAL, "bn_backward: channel pitches/offsets must be multiples of %d", vec);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
@@ -575,14 +588,14 @@ extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_co
   const RedGeom g = make_red(npix, 1, C, vec);
   DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
                                      static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
-                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, relu, g, partial));
+                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, relu, g, partial));
   if (int e = check_launch("bn_bwd_reduce")) return e;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, C, npix, gamma,
                      save_invstd, training, res_scale, dgamma, dbeta, coef);
   if (int e = check_launch("bn_bwd_finalize")) return e;
   DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
                                      static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
-                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, coef, relu,
+                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, coef, relu,
                                      static_cast<T*>(dx), static_cast<T*>(dres), g));
   return check_launch("bn_bwd_apply");
 }

@@ -146,8 +146,8 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
     return out, mean, invstd
 
 
-def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False):
-    """-> (dx, dres or None, dgamma, dbeta)."""
+def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False, beta=None):
+    """-> (dx, dres or None, dgamma, dbeta).  relu: False/0, True/1 (mask from y) or 2 (mask from x, needs beta)."""
     _chk(dy, "bn_backward")
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
@@ -159,6 +159,7 @@ def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, wa
     lib = _lib.load()
     _lib.check(lib.jspsr_bn_backward(dt, dy.data_ptr(), dy.shape[3], 0, y.data_ptr() if y is not None else None,
                                      y.shape[3] if y is not None else 0, 0, x.data_ptr(), C, 0, gamma.data_ptr(),
+                                     beta.data_ptr() if beta is not None else None,
                                      mean.data_ptr(), invstd.data_ptr(), int(training), int(relu), float(res_scale),
                                      dx.data_ptr(), dres.data_ptr() if dres is not None else None, dgamma.data_ptr(),
                                      dbeta.data_ptr(), B * H * W, C, ws.data_ptr(), _stream()), "jspsr_bn_backward")

@@ -194,16 +194,19 @@ class _BatchNorm(torch.autograd.Function):
         rs = float(res_scale) if res is not None else 1.0
         y, mean, invstd = K.bn_forward(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
                                        training, relu, res_c, rs)
-        ctx.cfg = (training, relu, rs, res is not None)
-        ctx.save_for_backward(x, y if relu else None, gamma.detach(), mean, invstd)
+        # without a residual the ReLU mask is a function of x alone: the backward recomputes it (mode 2)
+        # instead of reading the saved output
+        mode = 0 if not relu else (1 if res is not None else 2)
+        ctx.cfg = (training, mode, rs, res is not None)
+        ctx.save_for_backward(x, y if mode == 1 else None, gamma.detach(), beta.detach(), mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         training, relu, rs, has_res = ctx.cfg
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
         dx, dres, dgamma, dbeta = K.bn_backward(dy.contiguous(), y, x, gamma, mean, invstd, training, relu, rs,
-                                                want_dres=has_res and ctx.needs_input_grad[9])
+                                                want_dres=has_res and ctx.needs_input_grad[9], beta=beta)
         if has_res and ctx.needs_input_grad[9] and dres is None:
             dres = dy
         return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None
