@@ -89,11 +89,16 @@ int jspsr_pack_weight(int dtype, const float* w, void* packed, int O, int I, int
                       int mode, int c_pad, jspsr_stream_t stream);
 
 /* out[b,oy,ox,n] = bias[n] + sum_{ky,kx,c} in[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * W[n,ky,kx,c]
- * (+ ReLU if relu != 0).  wpack: mode-0 packing with c_pad = Cin.  bias may be NULL. */
+ * (+ ReLU if relu != 0).  wpack: mode-0 packing with c_pad = Cin.  bias may be NULL.
+ * stats (may be NULL; requires bias == NULL and relu == 0): the epilogue also writes the BatchNorm batch
+ * statistics of the result taken from the fp32 accumulators -- jspsr_conv2d_stats_rows(B,OH,OW) partial
+ * rows of [sum over the row's pixels | sum of squares] x Cout floats, to be handed to jspsr_bn_forward
+ * (ext_partial / ext_rows), which then skips its own pass over the tensor. */
+int jspsr_conv2d_stats_rows(int B, int OH, int OW);
 int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const float* bias, void* out,
                          int B, int IH, int IW, int Cin, int in_cstride, int in_coff, int Cout,
                          int out_cstride, int out_coff, int KH, int KW, int stride, int pad, int relu,
-                         jspsr_stream_t stream);
+                         float* stats, jspsr_stream_t stream);
 
 /* gin[b,y,x,c] = bias[c] + sum_{ky,kx,n} gout[b,(y+pad-ky)/stride,(x+pad-kx)/stride,n] * W[n,c,ky,kx]
  * over the taps where the division is exact: the data gradient of the conv above, and equally
@@ -132,12 +137,13 @@ size_t jspsr_reduce_workspace_bytes(int dtype, int C, int nseg);
  *   y = [relu]( bn(x) * res_scale + res )      (res may be NULL)
  * training != 0: batch statistics (biased var), running stats updated in place with `momentum`
  * (unbiased var), save_mean / save_invstd [C] written for the backward.  training == 0: running
- * stats are used (and copied to save_*). */
+ * stats are used (and copied to save_*).  ext_partial / ext_rows: statistics already accumulated by
+ * jspsr_conv2d_forward (NULL / 0: this call makes its own pass over x). */
 int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, const void* res, int r_cs, int r_coff,
                      void* y, int y_cs, int y_coff, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, int training,
                      int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
-                     void* workspace, jspsr_stream_t stream);
+                     const float* ext_partial, int ext_rows, void* workspace, jspsr_stream_t stream);
 
 /* Backward of the above.  dy is the gradient w.r.t. y.  relu: 0 = none; 1 = mask from the saved output
  * (y > 0); 2 = mask recomputed from x as gamma*xhat + beta > 0 (valid without a residual; y is not read).

@@ -45,8 +45,7 @@ class ConvUnit(nn.Module):
             x = self.camb(x)
         c = self.conv[0]
         if hasattr(self.conv, "bn"):
-            y = E.conv2d(x, c.weight, None, 1, self.k // 2)
-            return E.batch_norm(y, self.conv.bn, relu=self.relu)
+            return E.conv_bn(x, c.weight, self.conv.bn, 1, self.k // 2, relu=self.relu)
         return E.conv2d(x, c.weight, c.bias, 1, self.k // 2, relu=self.relu)  # bias + ReLU in the epilogue
 
 
@@ -81,12 +80,9 @@ class ResUnit(nn.Module):
         self.stride, self.act, self.scale = stride, act, scale
 
     def forward(self, x):
-        y = E.conv2d(x, self.conv1.weight, None, self.stride, 1)
-        y = E.batch_norm(y, self.bn1, relu=True)
-        y = E.conv2d(y, self.conv2.weight, None, 1, 1)
+        y = E.conv_bn(x, self.conv1.weight, self.bn1, self.stride, 1, relu=True)
         if self.downsample is not None:
-            r = E.conv2d(x, self.downsample[0].weight, None, self.stride, 0)
-            r = E.batch_norm(r, self.downsample[1])
+            r = E.conv_bn(x, self.downsample[0].weight, self.downsample[1], self.stride, 0)
         else:
             r = x
-        return E.batch_norm(y, self.bn2, relu=self.act, residual=r, res_scale=self.scale)
+        return E.conv_bn(y, self.conv2.weight, self.bn2, 1, 1, relu=self.act, residual=r, res_scale=self.scale)

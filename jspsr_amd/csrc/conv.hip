@@ -35,6 +35,52 @@ __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
 
 
+// BatchNorm statistics from the accumulators (fp32, before rounding to the storage type): per output
+// channel, sum and sum of squares over the tile's valid rows -> one partial row per M-tile,
+// stats[(tile * 2 + {0,1}) * Cout + n].  Lanes lr/lr+32 hold the two row halves of a column, the WGM
+// wave rows are folded through LDS; fixed order -> reproducible.
+template <int MI, int NI, int WGM, int WTM, int WTN, int BN, typename OutPix>
+__device__ __forceinline__ void stats_epilogue(const f32x16 (&acc)[MI][NI], float* __restrict__ stats, char* scratch,
+                                               int tile, int Cout, int n0, int wm, int wn, int lr, int lh,
+                                               OutPix&& out_pixel) {
+  float* red = reinterpret_cast<float*>(scratch);   // [WGM][2][BN]
+  float s[NI], q[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) s[ni] = q[ni] = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (out_pixel(row) < 0) continue;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float v = acc[mi][ni][e];
+        s[ni] += v;
+        q[ni] += v * v;
+      }
+    }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    s[ni] += __shfl_xor(s[ni], 32, 64);
+    q[ni] += __shfl_xor(q[ni], 32, 64);
+    if (lh == 0) {
+      red[(wm * 2 + 0) * BN + wn * WTN + ni * 32 + lr] = s[ni];
+      red[(wm * 2 + 1) * BN + wn * WTN + ni * 32 + lr] = q[ni];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * BN; i += NT) {
+    const int which = i / BN, col = i % BN;
+    if (n0 + col >= Cout) continue;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WGM; ++w) t += red[(w * 2 + which) * BN + col];
+    stats[((size_t)tile * 2 + which) * Cout + n0 + col] = t;
+  }
+  __syncthreads();
+}
+
 // UNI: Cin is a multiple of the stage depth BK, so every 16-byte chunk of a stage belongs to the
 // same tap -> the tap walk is wave-uniform (scalar registers, scalar offset of the buffer loads).
 // NBUF: LDS staging buffers.  2 = one barrier per stage; 1 = two barriers per stage but half the LDS,
@@ -44,7 +90,7 @@ template <typename T, int BM, int BN, int WGM, int WGN, bool UNI, int NBUF>
 __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const T* __restrict__ in,
                                                           const T* __restrict__ wgt,
                                                           const float* __restrict__ bias,
-                                                          T* __restrict__ out, ConvGeom g) {
+                                                          T* __restrict__ out, float* __restrict__ stats, ConvGeom g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int EPC = Elem<T>::EPC, BK = NCH * EPC;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
@@ -258,6 +304,10 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
     const int oy = y * g.oy_mul + g.oy_add, ox = x * g.ox_mul + g.ox_add;
     return (y < g.MH && x < g.MW && oy < g.OH && ox < g.OW) ? ((long long)bimg * g.OH + oy) * g.OW + ox : -1;
   };
+  if (stats) {
+    if (NBUF == 1) __syncthreads();
+    stats_epilogue<MI, NI, WGM, WTM, WTN, BN>(acc, stats, smem, mt, g.Cout, n0, wm, wn, lr, lh, out_pixel);
+  }
   float bv[NI];
   int ncol[NI];
 #pragma unroll
@@ -329,7 +379,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
 template <typename T, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                           const float* __restrict__ bias, T* __restrict__ out,
-                                                          ConvGeom g) {
+                                                          float* __restrict__ stats, ConvGeom g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 128, TLW = 16, TLH = BM / TLW;
   constexpr int EPC = Elem<T>::EPC, BK = NCH * EPC;
@@ -508,6 +558,7 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
     const int oy = y * g.oy_mul + g.oy_add, ox = x * g.ox_mul + g.ox_add;
     return (y < g.MH && x < g.MW && oy < g.OH && ox < g.OW) ? ((long long)bimg * g.OH + oy) * g.OW + ox : -1;
   };
+  if (stats) stats_epilogue<MI, NI, WGM, WTM, WTN, BN>(acc, stats, smem, mt, g.Cout, n0, wm, wn, lr, lh, out_pixel);
   float bv[NI];
   int ncol[NI];
 #pragma unroll
@@ -564,7 +615,7 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
 }
 
 template <typename T, int BN, int WGM, int WGN>
-int launch_patch(const void* in, const void* wgt, const float* bias, void* out, const ConvGeom& g, hipStream_t s) {
+int launch_patch(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
   constexpr int BM = 128, TLW = 16, TLH = BM / TLW, MAXPIX = 6 * NT / NCH;
   const long long nblk = (long long)g.B * ((g.MH + TLH - 1) / TLH) * ((g.MW + TLW - 1) / TLW) * ((g.Cout + BN - 1) / BN);
   if (nblk > 0x7fffffffLL) return fail(JSPSR_EINVAL, "conv: grid too large");
@@ -577,12 +628,12 @@ int launch_patch(const void* in, const void* wgt, const float* bias, void* out, 
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, s, static_cast<const T*>(in), static_cast<const T*>(wgt),
-                     bias, static_cast<T*>(out), g);
+                     bias, static_cast<T*>(out), stats, g);
   return check_launch("conv_patch");
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int NBUF>
-int launch_cfg(const void* in, const void* wgt, const float* bias, void* out, const ConvGeom& g, hipStream_t s) {
+int launch_cfg(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
   if ((long long)g.B * g.MH * g.MW <= 0) return JSPSR_OK;
   constexpr int TLW = 16, TLH = BM / TLW;
   const long long nblk = (long long)g.B * ((g.MH + TLH - 1) / TLH) * ((g.MW + TLW - 1) / TLW) * ((g.Cout + BN - 1) / BN);
@@ -600,15 +651,15 @@ int launch_cfg(const void* in, const void* wgt, const float* bias, void* out, co
   }
   if (g.Cin % BK == 0)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, true, NBUF>), dim3((unsigned)nblk), dim3(NT), lds, s,
-                       static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), g);
+                       static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), stats, g);
   else
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WGM, WGN, false, NBUF>), dim3((unsigned)nblk), dim3(NT), lds, s,
-                       static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), g);
+                       static_cast<const T*>(in), static_cast<const T*>(wgt), bias, static_cast<T*>(out), stats, g);
   return check_launch("conv_igemm");
 }
 
 template <typename T>
-int launch(const void* in, const void* wgt, const float* bias, void* out, const ConvGeom& g, hipStream_t s) {
+int launch(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
   // narrow tiles: single LDS buffer (4 resident workgroups per CU) while K is short -- the layer is then
   // HBM/latency bound and overlap across workgroups wins; double buffer for long K (measured crossover
   // between K = 576 and K = 2304 on MI355X).  JSPSR_CONV_NBUF overrides for experiments.
@@ -617,19 +668,19 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, const 
   constexpr int BKT = NCH * Elem<T>::EPC;
   if (!no_patch && g.iy_mul == 1 && g.ix_mul == 1 && g.nty >= 1 && g.ntx >= 1 && g.nty <= 3 && g.ntx <= 3 &&
       g.nty * g.ntx > 1 && g.Cin % BKT == 0 && (long long)(g.IW + 20) * 12 * g.in_cstride * (long long)sizeof(T) < 0xE0000000LL) {
-    if (g.Cout > 64) return launch_patch<T, 128, 2, 2>(in, wgt, bias, out, g, s);
-    if (g.Cout > 32) return launch_patch<T, 64, 2, 2>(in, wgt, bias, out, g, s);
-    return launch_patch<T, 32, 4, 1>(in, wgt, bias, out, g, s);
+    if (g.Cout > 64) return launch_patch<T, 128, 2, 2>(in, wgt, bias, out, stats, g, s);
+    if (g.Cout > 32) return launch_patch<T, 64, 2, 2>(in, wgt, bias, out, stats, g, s);
+    return launch_patch<T, 32, 4, 1>(in, wgt, bias, out, stats, g, s);
   }
   static const int nbuf_env = [] { const char* e = getenv("JSPSR_CONV_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf_narrow = nbuf_env ? nbuf_env : ((long long)g.nty * g.ntx * g.Cin <= 1152 ? 1 : 2);
-  if (g.Cout > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(in, wgt, bias, out, g, s);
+  if (g.Cout > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(in, wgt, bias, out, stats, g, s);
   if (nbuf_narrow == 2) {
-    if (g.Cout > 32) return launch_cfg<T, 128, 64, 2, 2, 2>(in, wgt, bias, out, g, s);
-    return launch_cfg<T, 128, 32, 4, 1, 2>(in, wgt, bias, out, g, s);
+    if (g.Cout > 32) return launch_cfg<T, 128, 64, 2, 2, 2>(in, wgt, bias, out, stats, g, s);
+    return launch_cfg<T, 128, 32, 4, 1, 2>(in, wgt, bias, out, stats, g, s);
   }
-  if (g.Cout > 32) return launch_cfg<T, 128, 64, 2, 2, 1>(in, wgt, bias, out, g, s);
-  return launch_cfg<T, 128, 32, 4, 1, 1>(in, wgt, bias, out, g, s);
+  if (g.Cout > 32) return launch_cfg<T, 128, 64, 2, 2, 1>(in, wgt, bias, out, stats, g, s);
+  return launch_cfg<T, 128, 32, 4, 1, 1>(in, wgt, bias, out, stats, g, s);
 }
 
 int check_common(int dtype, const void* a, const void* w, const void* o, int cin, int cs_in, int co_in,
@@ -682,10 +733,15 @@ extern "C" int jspsr_pack_weight(int dtype, const float* w, void* packed, int O,
   return check_launch("pack_weight");
 }
 
+extern "C" int jspsr_conv2d_stats_rows(int B, int OH, int OW) {
+  if (B <= 0 || OH <= 0 || OW <= 0) return 0;
+  return B * ((OH + 7) / 8) * ((OW + 15) / 16);   // one partial row per 8x16-pixel M-tile
+}
+
 extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const float* bias, void* out,
                                     int B, int IH, int IW, int Cin, int in_cstride, int in_coff, int Cout,
                                     int out_cstride, int out_coff, int KH, int KW, int stride, int pad, int relu,
-                                    jspsr_stream_t stream) {
+                                    float* stats, jspsr_stream_t stream) {
   if (int e = check_common(dtype, in, wpack, out, Cin, in_cstride, in_coff, out_cstride, out_coff, Cout, "conv2d_forward")) return e;
   if (B <= 0 || IH <= 0 || IW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     return fail(JSPSR_EINVAL, "conv2d_forward: bad geometry");
@@ -701,7 +757,8 @@ extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack
   g.oy_mul = 1; g.oy_add = 0; g.ox_mul = 1; g.ox_add = 0; g.relu = relu;
   g.accumulate = getenv("JSPSR_CONV_NOXCD") ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == JSPSR_F32 ? launch<float>(in, wpack, bias, out, g, s) : launch<__bf16>(in, wpack, bias, out, g, s);
+  if (stats && (bias || relu)) return fail(JSPSR_EINVAL, "conv2d_forward: statistics are taken from the raw accumulators (no bias / ReLU)");
+  return dtype == JSPSR_F32 ? launch<float>(in, wpack, bias, out, stats, g, s) : launch<__bf16>(in, wpack, bias, out, stats, g, s);
 }
 
 extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,
@@ -730,7 +787,8 @@ extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack
       g.iy_mul = 1; g.iy_add = (py + pad - g.ky0) / stride; g.ix_mul = 1; g.ix_add = (px + pad - g.kx0) / stride;
       g.sign = -1; g.KH = KH; g.KW = KW;
       g.oy_mul = stride; g.oy_add = py; g.ox_mul = stride; g.ox_add = px; g.relu = relu;
-      const int e = dtype == JSPSR_F32 ? launch<float>(gout, wpack_t, bias, gin, g, s) : launch<__bf16>(gout, wpack_t, bias, gin, g, s);
+      const int e = dtype == JSPSR_F32 ? launch<float>(gout, wpack_t, bias, gin, nullptr, g, s)
+                                       : launch<__bf16>(gout, wpack_t, bias, gin, nullptr, g, s);
       if (e) return e;
     }
   return JSPSR_OK;

@@ -198,6 +198,16 @@ __global__ __launch_bounds__(TX * TY) void bn_stats_kernel(const T* __restrict__
   });
 }
 
+// out[r][j] = sum of in[i][j] over rows i == r (mod nout): folds many partial rows into nout rows,
+// fixed order, coalesced along j
+__global__ void fold_rows_kernel(const float* __restrict__ in, int nin, int width, int nout, float* __restrict__ out) {
+  const int r = blockIdx.x, j = blockIdx.y * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  float s = 0.f;
+  for (int i = r; i < nin; i += nout) s += in[(size_t)i * width + j];
+  out[(size_t)r * width + j] = s;
+}
+
 // mean / biased var from the partial rows; running stats (momentum, unbiased var); scale/shift.
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, long long count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -538,7 +548,7 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
                                 void* y, int y_cs, int y_coff, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, int training,
                                 int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
-                                void* workspace, jspsr_stream_t stream) {
+                                const float* ext_partial, int ext_rows, void* workspace, jspsr_stream_t stream) {
   if (int e = check_c(dtype, C, "bn_forward")) return e;
   if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || npix <= 0)
     return fail(JSPSR_EINVAL, "bn_forward: null pointer or empty tensor");
@@ -552,7 +562,18 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
   float* shift = ws + C;
   float* partial = ws + 2 * C;
   int rows = 0;
-  if (training) {
+  if (training && ext_partial) {
+    // statistics were accumulated by the producing convolution's epilogue (one row per M-tile):
+    // fold them to <= 256 rows first so the per-channel finalize stays short
+    if (ext_rows <= 0) return fail(JSPSR_EINVAL, "bn_forward: ext_rows must be positive");
+    rows = ext_rows < 256 ? ext_rows : 256;
+    if (ext_rows > 256) {
+      hipLaunchKernelGGL(fold_rows_kernel, dim3(rows, (2 * C + 255) / 256), dim3(256), 0, s, ext_partial, ext_rows, 2 * C, rows, partial);
+      if (int e = check_launch("bn_fold_rows")) return e;
+    } else {
+      (void)hipMemcpyAsync(partial, ext_partial, (size_t)ext_rows * 2 * C * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
+  } else if (training) {
     const RedGeom g = make_red(npix, 1, C, vec);
     rows = g.chunks;
     DISPATCH(dtype, hipLaunchKernelGGL(bn_stats_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,

@@ -48,8 +48,10 @@ def pack_weight(w: torch.Tensor, mode: int, c_pad: int, dtype: torch.dtype) -> t
     return out
 
 
-def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0, cin=None, in_coff=0):
-    """x (B,IH,IW,Cs) NHWC, wpack [Cout][KH][KW][Cin] -> (B,OH,OW,Cout) (or a slice of `out`)."""
+def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0, cin=None, in_coff=0, stats=False):
+    """x (B,IH,IW,Cs) NHWC, wpack [Cout][KH][KW][Cin] -> (B,OH,OW,Cout) (or a slice of `out`).
+    stats=True (no bias / ReLU): also returns the BatchNorm partial statistics (rows, 2, Cout) fp32 taken from
+    the accumulators in the epilogue."""
     _chk(x, "conv2d_forward")
     B, IH, IW, Cs = x.shape
     Cout, KH, KW, Cin = wpack.shape
@@ -60,11 +62,15 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
     if out is None:
         out = torch.empty((B, OH, OW, Cout), dtype=x.dtype, device=x.device)
     lib = _lib.load()
+    st = None
+    if stats:
+        st = torch.empty((lib.jspsr_conv2d_stats_rows(B, OH, OW), 2, Cout), dtype=torch.float32, device=x.device)
     _lib.check(lib.jspsr_conv2d_forward(_dt(x), x.data_ptr(), wpack.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                         B, IH, IW, Cin, Cs, in_coff, Cout, out.shape[3], out_coff,
-                                        KH, KW, stride, pad, int(relu), _stream()), "jspsr_conv2d_forward")
-    return out
+                                        KH, KW, stride, pad, int(relu), st.data_ptr() if st is not None else None,
+                                        _stream()), "jspsr_conv2d_forward")
+    return (out, st) if stats else out
 
 
 def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0):
@@ -124,8 +130,9 @@ def _workspace(dtype_code: int, C: int, nseg: int, device) -> torch.Tensor:
 
 
 def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu=False, res=None,
-               res_scale=1.0, out=None, out_coff=0):
-    """x (B,H,W,C) -> y = [relu](bn(x)*res_scale + res); returns (y, save_mean, save_invstd)."""
+               res_scale=1.0, out=None, out_coff=0, partial=None):
+    """x (B,H,W,C) -> y = [relu](bn(x)*res_scale + res); returns (y, save_mean, save_invstd).
+    partial: (rows, 2, C) statistics from conv2d_forward(stats=True) -- skips the statistics pass."""
     _chk(x, "bn_forward")
     B, H, W, C = x.shape
     if out is None:
@@ -141,7 +148,9 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
                                     running_mean.data_ptr() if running_mean is not None else None,
                                     running_var.data_ptr() if running_var is not None else None,
                                     float(momentum), float(eps), int(training), int(relu), float(res_scale),
-                                    mean.data_ptr(), invstd.data_ptr(), B * H * W, C, ws.data_ptr(), _stream()),
+                                    mean.data_ptr(), invstd.data_ptr(), B * H * W, C,
+                                    partial.data_ptr() if partial is not None else None,
+                                    partial.shape[0] if partial is not None else 0, ws.data_ptr(), _stream()),
                "jspsr_bn_forward")
     return out, mean, invstd
 

@@ -115,7 +115,7 @@ class _Conv(torch.autograd.Function):
     with the bias + ReLU of a BN-free Basic2d fused into the epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, transposed):
+    def forward(ctx, x, weight, bias, stride, pad, relu, transposed, want_stats=False):
         x = x.contiguous()
         cdt = x.dtype
         e = K.epc(cdt)
@@ -128,7 +128,13 @@ class _Conv(torch.autograd.Function):
             O, I, KH, KW = w.shape
             if Cp < I:
                 raise ValueError("conv: input has fewer channels than the weight")
-            y = K.conv2d_forward(x, K.pack_weight(w, 0, Cp, cdt), bias_d, stride, pad, relu)
+            y = K.conv2d_forward(x, K.pack_weight(w, 0, Cp, cdt), bias_d, stride, pad, relu, stats=want_stats)
+            if want_stats:
+                y, st = y
+                ctx.cfg = (stride, pad, relu, transposed, bias is not None)
+                ctx.save_for_backward(x, w, None)
+                ctx.mark_non_differentiable(st)
+                return y, st
         else:
             I, O, KH, KW = w.shape  # ConvTranspose2d weight layout
             if Cp != I or stride != 2 or pad != 1 or KH != 3:
@@ -139,7 +145,7 @@ class _Conv(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         stride, pad, relu, transposed, has_bias = ctx.cfg
         x, w, y = ctx.saved_tensors
         cdt = x.dtype
@@ -173,11 +179,17 @@ class _Conv(torch.autograd.Function):
                 dx = K.conv2d_forward(dz, K.pack_weight(w, 0, Cg, cdt), None, 2, 1, False)
             if ctx.needs_input_grad[1]:
                 dW = K.conv2d_wgrad(x, dz, I, O, KH, KW, 2, 1)
-        return dx, dW, dbias, None, None, None, None
+        return dx, dW, dbias, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
     return _Conv.apply(x, weight, bias, stride, pad, relu, False)
+
+
+def conv2d_with_stats(x, weight, stride=1, pad=0):
+    """Bias-free conv that also returns the BatchNorm partial statistics of its output (from the fp32
+    accumulators in the epilogue) -> feeds batch_norm(..., partial=...)."""
+    return _Conv.apply(x, weight, None, stride, pad, False, False, True)
 
 
 def conv_transpose2d(x, weight):
@@ -188,12 +200,13 @@ class _BatchNorm(torch.autograd.Function):
     """y = [relu](BatchNorm2d(x) * res_scale + res), basics.py:111-123."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale,
+                partial=None):
         x = x.contiguous()
         res_c = res.contiguous() if res is not None else None
         rs = float(res_scale) if res is not None else 1.0
         y, mean, invstd = K.bn_forward(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
-                                       training, relu, res_c, rs)
+                                       training, relu, res_c, rs, partial=partial if training else None)
         # without a residual the ReLU mask is a function of x alone: the backward recomputes it (mode 2)
         # instead of reading the saved output
         mode = 0 if not relu else (1 if res is not None else 2)
@@ -209,11 +222,13 @@ class _BatchNorm(torch.autograd.Function):
                                                 want_dres=has_res and ctx.needs_input_grad[9], beta=beta)
         if has_res and ctx.needs_input_grad[9] and dres is None:
             dres = dy
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None
 
 
-def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu=False, res=None, res_scale=1.0):
-    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale)
+def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu=False, res=None, res_scale=1.0,
+               partial=None):
+    return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale,
+                            partial)
 
 
 def _gate_mlp(avg, mx, w1, w2):

@@ -156,3 +156,23 @@ def test_bad_arguments_raise():
         K.conv2d_forward(x, wp, None, 1, 1)
     with pytest.raises(RuntimeError):
         K.conv2d_forward(torch.zeros(1, 8, 8, 8), wp, None, 1, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", [(2, 33, 47, 32, 32, 3, 1, 1), (1, 40, 36, 64, 128, 3, 1, 1),
+                                                         (2, 16, 16, 64, 128, 1, 2, 0), (1, 24, 24, 16, 200, 3, 2, 1)])
+def test_conv_epilogue_statistics(dtype, B, H, W, Cin, Cout, k, stride, pad):
+    """BatchNorm partial sums written by the conv epilogue == sums of the fp32 result."""
+    K = _k()
+    if Cin % K.epc(dtype):
+        pytest.skip("channel granularity")
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    y, st = K.conv2d_forward(_nhwc(x).to(dtype), K.pack_weight(w.cuda(), 0, Cin, dtype), None, stride, pad, stats=True)
+    s = st.double().sum(0).cpu()
+    assert _relerr(s[0], ref.sum((0, 2, 3))) < 1e-4
+    assert _relerr(s[1], (ref * ref).sum((0, 2, 3))) < 1e-5
