@@ -286,7 +286,13 @@ __global__ __launch_bounds__(TX * TY) void bn_bwd_reduce_kernel(const T* __restr
                                                                float* __restrict__ partial) {
   constexpr int N = V<T>::N;
   // relu == 1: mask from the saved output y;  relu == 2 (no residual): mask recomputed from x,
-  // [gamma*xhat + beta > 0], which saves reading y
+  // [gamma*xhat + beta > 0], which saves reading y.  Per-channel parameters live in registers.
+  float mu[N], is[N], ga[N], be[N];
+  const int c0 = lane_map<N>(g).c;
+  if (c0 < g.C) {
+    load_param<N>(mean + c0, mu); load_param<N>(invstd + c0, is);
+    if (relu == 2) { load_param<N>(gamma + c0, ga); load_param<N>(beta + c0, be); }
+  }
   reduce_pixels<T, 2>(g, partial, [&](long long pix, int c, float (&acc)[2][N]) {
     float d[N], xv[N], yv[N];
     load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
@@ -294,8 +300,8 @@ __global__ __launch_bounds__(TX * TY) void bn_bwd_reduce_kernel(const T* __restr
     if (relu == 1) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const float xhat = (xv[i] - mean[c + i]) * invstd[c + i];
-      const bool off = relu == 1 ? !(yv[i] > 0.f) : (relu == 2 ? !(gamma[c + i] * xhat + beta[c + i] > 0.f) : false);
+      const float xhat = (xv[i] - mu[i]) * is[i];
+      const bool off = relu == 1 ? !(yv[i] > 0.f) : (relu == 2 ? !(ga[i] * xhat + be[i] > 0.f) : false);
       const float dz = off ? 0.f : d[i];
       acc[0][i] += dz;
       acc[1][i] += dz * xhat;
