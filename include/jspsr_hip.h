@@ -156,8 +156,9 @@ int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const v
                       jspsr_stream_t stream);
 
 /* Backward of the conv epilogue `y = [relu](conv + bias)` of the BN-free Basic2d (basics.py:36-53):
- * dz = dy * [y > 0] (written with pitch dz_cs if dz != NULL), dbias[c] = sum dz (if dbias != NULL). */
-int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int relu, void* dz,
+ * dz = dy * [y > 0] (y read with channel pitch y_cs; dz written with pitch dz_cs if dz != NULL),
+ * dbias[c] = sum dz (if dbias != NULL). */
+int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int relu, void* dz,
                        int dz_cs, float* dbias, long long npix, int C, void* workspace, jspsr_stream_t stream);
 
 /* ChannelAttention (models/components/resnet_cbam.py:36-53; applied in basics.py:57-58).

@@ -138,17 +138,33 @@ class Model(nn.Module):
         order = [b for b in self._branches if b in feats]
         if len(order) < 2:
             raise NotImplementedError
-        fused = []
-        for s in range(1, 5):  # JSPSR.py:230-352
+        # The reference concatenates per stage (Guide cat_only, :230-352) and again in the decoder (:354-368).
+        # Here each stage owns one wide NHWC buffer [up | dem | img | aux]; the last unit of every branch and the
+        # decoder's UpUnit write their channel slice of it directly, so neither concat moves any data.
+        B, H, W = dem_a.shape[:3]
+        nb, nf2 = len(order), self.conv0.conv[0].out_channels
+        bufs, fused, joined = [], [], []
+        for s in range(1, 5):
+            planes = nf2 * 2 ** (s - 1)
+            if s > 1:
+                H, W = (H + 1) // 2, (W + 1) // 2  # 3x3 stride-2 pad-1 (k1 projection: same size)
+            lead = planes if s < 4 else 0       # room for the decoder's up-sampled features
+            buf = E.SliceBuffer(B, H, W, lead + nb * planes, dem_a.dtype, dem_a.device)
             nxt = {}
-            for br in order:
+            for i, br in enumerate(order):
                 src = fused[-1] if (br == "dem" and fused) else feats[br]
-                nxt[br] = getattr(self, f"layer{s}_{br}")(src)
+                units = getattr(self, f"layer{s}_{br}")
+                for u in list(units)[:-1]:
+                    src = u(src)
+                nxt[br] = units[-1](src, dest=(buf, lead + i * planes))
             feats = nxt
-            fused.append(E.cat([feats[b] for b in order]))
+            bufs.append((buf, lead))
+            joined.append([feats[b] for b in order])
+            fused.append(buf.join(joined[-1], lead))
         x = fused[3]
-        for up, skip in ((self.layer3d, fused[2]), (self.layer2d, fused[1]), (self.layer1d, fused[0])):
-            x = E.cat((up(x), skip))  # :354-368
+        for up, s in ((self.layer3d, 2), (self.layer2d, 1), (self.layer1d, 0)):
+            buf, lead = bufs[s]
+            x = buf.join([up(x, dest=(buf, 0))] + joined[s], 0)  # cat((up, skip)), :354-368
         c0 = self.conv0(x)
         dem = dem.detach()  # :372
         weight, off16 = self.generator.heads(self.generator.features(dem_a.detach(), c0))

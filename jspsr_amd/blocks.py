@@ -40,13 +40,13 @@ class ConvUnit(nn.Module):
         self.k = kernel_size
         self.relu = relu
 
-    def forward(self, x):
+    def forward(self, x, dest=None):
         if hasattr(self, "camb"):
             x = self.camb(x)
         c = self.conv[0]
         if hasattr(self.conv, "bn"):
-            return E.conv_bn(x, c.weight, self.conv.bn, 1, self.k // 2, relu=self.relu)
-        return E.conv2d(x, c.weight, c.bias, 1, self.k // 2, relu=self.relu)  # bias + ReLU in the epilogue
+            return E.conv_bn(x, c.weight, self.conv.bn, 1, self.k // 2, relu=self.relu, dest=dest)
+        return E.conv2d(x, c.weight, c.bias, 1, self.k // 2, relu=self.relu, dest=dest)  # bias + ReLU in the epilogue
 
 
 class UpUnit(nn.Module):
@@ -59,10 +59,10 @@ class UpUnit(nn.Module):
         self.dconv.add_module("1", nn.ConvTranspose2d(cout, cout, 3, 2, 1, 1, bias=False))
         self.dconv.add_module("bn", nn.BatchNorm2d(cout))
 
-    def forward(self, x):
+    def forward(self, x, dest=None):
         y = self.dconv[0](x)
         y = E.conv_transpose2d(y, self.dconv[1].weight)
-        return E.batch_norm(y, self.dconv.bn, relu=True)
+        return E.batch_norm(y, self.dconv.bn, relu=True, dest=dest)
 
 
 class ResUnit(nn.Module):
@@ -79,10 +79,11 @@ class ResUnit(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
         self.stride, self.act, self.scale = stride, act, scale
 
-    def forward(self, x):
+    def forward(self, x, dest=None):
         y = E.conv_bn(x, self.conv1.weight, self.bn1, self.stride, 1, relu=True)
         if self.downsample is not None:
             r = E.conv_bn(x, self.downsample[0].weight, self.downsample[1], self.stride, 0)
         else:
             r = x
-        return E.conv_bn(y, self.conv2.weight, self.bn2, 1, 1, relu=self.act, residual=r, res_scale=self.scale)
+        return E.conv_bn(y, self.conv2.weight, self.bn2, 1, 1, relu=self.act, residual=r, res_scale=self.scale,
+                         dest=dest)

@@ -366,13 +366,14 @@ __global__ __launch_bounds__(TX * TY) void bn_bwd_apply_kernel(const T* __restri
 // ---------------------------------------------------------------- ReLU backward + bias gradient
 template <typename T>
 __global__ __launch_bounds__(TX * TY) void act_bwd_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
-                                                         const T* __restrict__ y, int relu, T* __restrict__ dz,
-                                                         int dz_cs, RedGeom g, float* __restrict__ partial) {
+                                                         const T* __restrict__ y, int y_cs, int relu,
+                                                         T* __restrict__ dz, int dz_cs, RedGeom g,
+                                                         float* __restrict__ partial) {
   constexpr int N = V<T>::N;
   reduce_pixels<T, 1>(g, partial, [&](long long pix, int c, float (&acc)[1][N]) {
     float d[N], yv[N];
     load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
-    if (relu) load_vec<T>(y + (size_t)pix * g.C + c, yv);
+    if (relu) load_vec<T>(y + (size_t)pix * y_cs + c, yv);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       if (relu && !(yv[i] > 0.f)) d[i] = 0.f;
@@ -627,17 +628,19 @@ extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_co
   return check_launch("bn_bwd_apply");
 }
 
-extern "C" int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int relu, void* dz,
-                                  int dz_cs, float* dbias, long long npix, int C, void* workspace, jspsr_stream_t stream) {
+extern "C" int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int relu,
+                                  void* dz, int dz_cs, float* dbias, long long npix, int C, void* workspace,
+                                  jspsr_stream_t stream) {
   if (int e = check_c(dtype, C, "act_backward")) return e;
   if (!dy || (relu && !y) || !workspace || npix <= 0) return fail(JSPSR_EINVAL, "act_backward: null pointer or empty tensor");
   const int vec = dtype == JSPSR_F32 ? 4 : 8;
-  if (dy_cs % vec || dy_coff % vec || (dz && dz_cs % vec)) return fail(JSPSR_EINVAL, "act_backward: bad pitch");
+  if (dy_cs % vec || dy_coff % vec || (dz && dz_cs % vec) || (relu && (y_cs % vec || y_cs < C)))
+    return fail(JSPSR_EINVAL, "act_backward: bad pitch");
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   const RedGeom g = make_red(npix, 1, C, vec);
   DISPATCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s, static_cast<const T*>(dy),
-                                     dy_cs, dy_coff, static_cast<const T*>(y), relu, static_cast<T*>(dz), dz_cs, g, partial));
+                                     dy_cs, dy_coff, static_cast<const T*>(y), y_cs, relu, static_cast<T*>(dz), dz_cs, g, partial));
   if (int e = check_launch("act_backward")) return e;
   if (dbias) {
     hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, 1, 0, C, dbias);

@@ -57,8 +57,11 @@ def to_nchw_f32(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 3, 1, 2).float().contiguous()
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
-    return ops.conv2d(x, weight, bias, stride, padding, relu)
+SliceBuffer = ops.SliceBuffer
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False, dest=None):
+    return ops.conv2d(x, weight, bias, stride, padding, relu, dest)
 
 
 def conv_transpose2d(x, weight):
@@ -66,22 +69,23 @@ def conv_transpose2d(x, weight):
     return ops.conv_transpose2d(x, weight)
 
 
-def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, res_scale=1.0, partial=None):
-    """BatchNorm2d (+ `* res_scale + residual`) (+ ReLU): basics.py:113-123."""
+def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, res_scale=1.0, partial=None, dest=None):
+    """BatchNorm2d (+ `* res_scale + residual`) (+ ReLU): basics.py:113-123.  dest = (SliceBuffer, channel):
+    write the result into that channel slice instead of a fresh tensor."""
     training = bn.training or bn.running_mean is None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training,
-                          relu, residual, res_scale, partial)
+                          relu, residual, res_scale, partial, dest)
 
 
-def conv_bn(x, weight, bn: torch.nn.BatchNorm2d, stride=1, padding=0, relu=False, residual=None, res_scale=1.0):
+def conv_bn(x, weight, bn: torch.nn.BatchNorm2d, stride=1, padding=0, relu=False, residual=None, res_scale=1.0, dest=None):
     """Bias-free conv -> BatchNorm (+residual, +ReLU).  In training mode the batch statistics come out of the
     convolution's epilogue (fp32 accumulators), so BatchNorm makes one pass over the tensor instead of two."""
     if bn.training or bn.running_mean is None:
         y, st = ops.conv2d_with_stats(x, weight, stride, padding)
-        return batch_norm(y, bn, relu, residual, res_scale, partial=st)
-    return batch_norm(ops.conv2d(x, weight, None, stride, padding), bn, relu, residual, res_scale)
+        return batch_norm(y, bn, relu, residual, res_scale, partial=st, dest=dest)
+    return batch_norm(ops.conv2d(x, weight, None, stride, padding), bn, relu, residual, res_scale, dest=dest)
 
 
 def channel_gate(x, w1, w2):

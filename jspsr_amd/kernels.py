@@ -36,6 +36,35 @@ def _chk(t: torch.Tensor, name: str):
         raise ValueError(f"{name}: expected a contiguous tensor")
 
 
+def is_slice(t: torch.Tensor) -> bool:
+    """(B,H,W,C) tensor that is a channel slice of a wider dense NHWC buffer: unit channel stride, one common
+    pixel pitch, 16-byte aligned rows.  The kernels address such a tensor as (pointer, pitch) -- no copy."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        return False
+    B, H, W, C = t.shape
+    p = t.stride(2)
+    if p < C or (H > 1 and t.stride(1) != W * p) or (B > 1 and t.stride(0) != H * W * p) or W == 1:
+        return False
+    return t.data_ptr() % 16 == 0 and (p * t.element_size()) % 16 == 0
+
+
+def pitch(t: torch.Tensor) -> int:
+    """Channel pitch (elements between consecutive pixels)."""
+    return t.shape[3] if t.is_contiguous() else t.stride(2)
+
+
+def nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` itself if the kernels can address it in place, else a dense copy."""
+    return t if (t.is_contiguous() or is_slice(t)) else t.contiguous()
+
+
+def _chk_s(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: jspsr_amd kernels run on the GPU only (no CPU fallback)")
+    if not (t.is_contiguous() or is_slice(t)):
+        raise ValueError(f"{name}: expected a dense NHWC tensor or a channel slice of one")
+
+
 def pack_weight(w: torch.Tensor, mode: int, c_pad: int, dtype: torch.dtype) -> torch.Tensor:
     """(O,I,KH,KW) fp32 master -> [O][KH][KW][c_pad] (mode 0) or [I][KH][KW][c_pad] (mode 1)."""
     _chk(w, "pack_weight")
@@ -52,8 +81,9 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
     """x (B,IH,IW,Cs) NHWC, wpack [Cout][KH][KW][Cin] -> (B,OH,OW,Cout) (or a slice of `out`).
     stats=True (no bias / ReLU): also returns the BatchNorm partial statistics (rows, 2, Cout) fp32 taken from
     the accumulators in the epilogue."""
-    _chk(x, "conv2d_forward")
-    B, IH, IW, Cs = x.shape
+    _chk_s(x, "conv2d_forward")
+    B, IH, IW, _ = x.shape
+    Cs = pitch(x)
     Cout, KH, KW, Cin = wpack.shape
     if cin is not None and cin != Cin:
         raise ValueError("conv2d_forward: cin mismatch")
@@ -67,7 +97,7 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
         st = torch.empty((lib.jspsr_conv2d_stats_rows(B, OH, OW), 2, Cout), dtype=torch.float32, device=x.device)
     _lib.check(lib.jspsr_conv2d_forward(_dt(x), x.data_ptr(), wpack.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, out.data_ptr(),
-                                        B, IH, IW, Cin, Cs, in_coff, Cout, out.shape[3], out_coff,
+                                        B, IH, IW, Cin, Cs, in_coff, Cout, pitch(out), out_coff,
                                         KH, KW, stride, pad, int(relu), st.data_ptr() if st is not None else None,
                                         _stream()), "jspsr_conv2d_forward")
     return (out, st) if stats else out
@@ -76,8 +106,9 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
 def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0):
     """g (B,OH,OW,Cgs) NHWC, wpack_t [Cin][KH][KW][Cg] -> (B,IH,IW,Cin): data gradient of a conv /
     forward of a transposed conv."""
-    _chk(g, "conv2d_dgrad")
-    B, OH, OW, Cgs = g.shape
+    _chk_s(g, "conv2d_dgrad")
+    B, OH, OW, _ = g.shape
+    Cgs = pitch(g)
     Cin, KH, KW, Cg = wpack_t.shape
     IH, IW = in_hw
     if out is None:
@@ -85,19 +116,20 @@ def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None
     lib = _lib.load()
     _lib.check(lib.jspsr_conv2d_dgrad(_dt(g), g.data_ptr(), wpack_t.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, out.data_ptr(),
-                                      B, OH, OW, Cg, Cgs, g_coff, IH, IW, Cin, out.shape[3], out_coff,
+                                      B, OH, OW, Cg, Cgs, g_coff, IH, IW, Cin, pitch(out), out_coff,
                                       KH, KW, stride, pad, int(relu), _stream()), "jspsr_conv2d_dgrad")
     return out
 
 
 def conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=None, accumulate=False, g_coff=0, cg=None, x_coff=0, cx=None):
     """dW (R,C,KH,KW) fp32 = sum_pixels G[.., r] * X[shifted.., c].  G (B,OH,OW,Cgs), X (B,IH,IW,Cxs) NHWC."""
-    _chk(G, "conv2d_wgrad")
-    _chk(X, "conv2d_wgrad")
-    B, OH, OW, Cgs = G.shape
-    _, IH, IW, Cxs = X.shape
-    cg = Cgs if cg is None else cg
-    cx = Cxs if cx is None else cx
+    _chk_s(G, "conv2d_wgrad")
+    _chk_s(X, "conv2d_wgrad")
+    B, OH, OW, Cg_ = G.shape
+    _, IH, IW, Cx_ = X.shape
+    Cgs, Cxs = pitch(G), pitch(X)
+    cg = Cg_ if cg is None else cg
+    cx = Cx_ if cx is None else cx
     if out is None:
         out = torch.empty((R, C, KH, KW), dtype=torch.float32, device=G.device)
     lib = _lib.load()
@@ -133,17 +165,17 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
                res_scale=1.0, out=None, out_coff=0, partial=None):
     """x (B,H,W,C) -> y = [relu](bn(x)*res_scale + res); returns (y, save_mean, save_invstd).
     partial: (rows, 2, C) statistics from conv2d_forward(stats=True) -- skips the statistics pass."""
-    _chk(x, "bn_forward")
+    _chk_s(x, "bn_forward")
     B, H, W, C = x.shape
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     dt = _dt(x)
     ws = _workspace(dt, C, 1, x.device)
     lib = _lib.load()
-    _lib.check(lib.jspsr_bn_forward(dt, x.data_ptr(), C, 0, res.data_ptr() if res is not None else None,
-                                    res.shape[3] if res is not None else 0, 0, out.data_ptr(), out.shape[3], out_coff,
+    _lib.check(lib.jspsr_bn_forward(dt, x.data_ptr(), pitch(x), 0, res.data_ptr() if res is not None else None,
+                                    pitch(res) if res is not None else 0, 0, out.data_ptr(), pitch(out), out_coff,
                                     gamma.data_ptr(), beta.data_ptr(),
                                     running_mean.data_ptr() if running_mean is not None else None,
                                     running_var.data_ptr() if running_var is not None else None,
@@ -157,17 +189,17 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
 
 def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False, beta=None):
     """-> (dx, dres or None, dgamma, dbeta).  relu: False/0, True/1 (mask from y) or 2 (mask from x, needs beta)."""
-    _chk(dy, "bn_backward")
+    _chk_s(dy, "bn_backward")
     B, H, W, C = x.shape
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_dres else None
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    dres = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device) if want_dres else None
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     dt = _dt(x)
     ws = _workspace(dt, C, 1, x.device)
     lib = _lib.load()
-    _lib.check(lib.jspsr_bn_backward(dt, dy.data_ptr(), dy.shape[3], 0, y.data_ptr() if y is not None else None,
-                                     y.shape[3] if y is not None else 0, 0, x.data_ptr(), C, 0, gamma.data_ptr(),
+    _lib.check(lib.jspsr_bn_backward(dt, dy.data_ptr(), pitch(dy), 0, y.data_ptr() if y is not None else None,
+                                     pitch(y) if y is not None else 0, 0, x.data_ptr(), pitch(x), 0, gamma.data_ptr(),
                                      beta.data_ptr() if beta is not None else None,
                                      mean.data_ptr(), invstd.data_ptr(), int(training), int(relu), float(res_scale),
                                      dx.data_ptr(), dres.data_ptr() if dres is not None else None, dgamma.data_ptr(),
@@ -177,7 +209,7 @@ def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, wa
 
 def act_backward(dy, y, relu, want_dz=True, want_dbias=True, dz_channels=None):
     """dz = dy*[y>0] (optionally into a wider, zero-initialised channel pitch), dbias = sum dz."""
-    _chk(dy, "act_backward")
+    _chk_s(dy, "act_backward")
     B, H, W, C = dy.shape
     dz = None
     if want_dz:
@@ -188,7 +220,10 @@ def act_backward(dy, y, relu, want_dz=True, want_dbias=True, dz_channels=None):
     dt = _dt(dy)
     ws = _workspace(dt, C, 1, dy.device)
     lib = _lib.load()
-    _lib.check(lib.jspsr_act_backward(dt, dy.data_ptr(), C, 0, y.data_ptr() if y is not None else None, int(relu),
+    if y is not None:
+        y = nhwc(y)
+    _lib.check(lib.jspsr_act_backward(dt, dy.data_ptr(), pitch(dy), 0, y.data_ptr() if y is not None else None,
+                                      pitch(y) if y is not None else 0, int(relu),
                                       dz.data_ptr() if dz is not None else None, dz.shape[3] if dz is not None else 0,
                                       dbias.data_ptr() if dbias is not None else None, B * H * W, C, ws.data_ptr(),
                                       _stream()), "jspsr_act_backward")

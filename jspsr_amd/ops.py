@@ -110,13 +110,57 @@ def pad_channels(x: torch.Tensor, mult: int) -> torch.Tensor:
     return x if p == 0 else torch.nn.functional.pad(x, (0, p))
 
 
+class SliceBuffer:
+    """A wide NHWC buffer that several operators fill channel slice by channel slice -- the reference's
+    ``torch.cat((a, b, c), 1)`` (Guide, basics.py:134; skip concats JSPSR.py:355-368; spn.py:63) without the copy.
+    Producers take ``dest=(buffer, first_channel)`` and return the slice they wrote; ``join`` returns the joined
+    tensor as an autograd node over the producers."""
+
+    def __init__(self, B, H, W, C, dtype, device):
+        self.buf = torch.empty((B, H, W, C), dtype=dtype, device=device)
+
+    def slice(self, lo, n, shape=None):
+        """The (B,H,W,n) channel slice starting at `lo`; `shape` = the (B,H,W) the producer is about to write."""
+        if lo < 0 or lo + n > self.buf.shape[3]:
+            raise ValueError(f"SliceBuffer: channels [{lo}, {lo + n}) outside a {self.buf.shape[3]}-channel buffer")
+        if shape is not None and tuple(shape) != tuple(self.buf.shape[:3]):
+            raise ValueError(f"SliceBuffer: producer shape {tuple(shape)} != buffer {tuple(self.buf.shape[:3])}")
+        v = self.buf.narrow(3, lo, n).detach()
+        if not (v.is_contiguous() or K.is_slice(v)):
+            raise ValueError("SliceBuffer: slice start / buffer width must be a multiple of 16 bytes")
+        return v
+
+    def join(self, parts, lo=0):
+        """parts: the tensors returned by the producers, in channel order starting at `lo`."""
+        return _Join.apply(self, lo, *parts)
+
+
+class _Join(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, lo, *parts):
+        ctx.widths = [p.shape[3] for p in parts]
+        n = sum(ctx.widths)
+        for p, w in zip(parts, ctx.widths):   # the producers must really have written into this buffer
+            if p.untyped_storage().data_ptr() != holder.buf.untyped_storage().data_ptr():
+                raise RuntimeError("SliceBuffer.join: a part does not live in this buffer")
+        return holder.buf.narrow(3, lo, n).detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(g.narrow(3, off, w))
+            off += w
+        return (None, None) + tuple(outs)
+
+
 class _Conv(torch.autograd.Function):
     """nn.Conv2d (basics.py:11-20,39-47) or nn.ConvTranspose2d k3 s2 p1 op1 (basics.py:69-77),
     with the bias + ReLU of a BN-free Basic2d fused into the epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, transposed, want_stats=False):
-        x = x.contiguous()
+    def forward(ctx, x, weight, bias, stride, pad, relu, transposed, want_stats=False, dest=None):
+        x = K.nhwc(x)
         cdt = x.dtype
         e = K.epc(cdt)
         B, H, W, Cp = x.shape
@@ -128,7 +172,10 @@ class _Conv(torch.autograd.Function):
             O, I, KH, KW = w.shape
             if Cp < I:
                 raise ValueError("conv: input has fewer channels than the weight")
-            y = K.conv2d_forward(x, K.pack_weight(w, 0, Cp, cdt), bias_d, stride, pad, relu, stats=want_stats)
+            out = None
+            if dest is not None:
+                out = dest[0].slice(dest[1], O, (B, (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1))
+            y = K.conv2d_forward(x, K.pack_weight(w, 0, Cp, cdt), bias_d, stride, pad, relu, stats=want_stats, out=out)
             if want_stats:
                 y, st = y
                 ctx.cfg = (stride, pad, relu, transposed, bias is not None)
@@ -139,6 +186,8 @@ class _Conv(torch.autograd.Function):
             I, O, KH, KW = w.shape  # ConvTranspose2d weight layout
             if Cp != I or stride != 2 or pad != 1 or KH != 3:
                 raise ValueError("conv_transpose: only k3 s2 p1 op1 without channel padding is built")
+            if dest is not None:
+                raise ValueError("conv_transpose: dest is not supported")
             y = K.conv2d_dgrad(x, K.pack_weight(w, 1, Cp, cdt), (2 * H, 2 * W), 2, 1, bias=bias_d, relu=relu)
         ctx.cfg = (stride, pad, relu, transposed, bias is not None)
         ctx.save_for_backward(x, w, y if relu else None)
@@ -150,7 +199,7 @@ class _Conv(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         cdt = x.dtype
         e = K.epc(cdt)
-        dy = dy.contiguous()
+        dy = K.nhwc(dy)
         Co = dy.shape[3]
         Cg = (Co + e - 1) // e * e
         dbias = None
@@ -179,11 +228,11 @@ class _Conv(torch.autograd.Function):
                 dx = K.conv2d_forward(dz, K.pack_weight(w, 0, Cg, cdt), None, 2, 1, False)
             if ctx.needs_input_grad[1]:
                 dW = K.conv2d_wgrad(x, dz, I, O, KH, KW, 2, 1)
-        return dx, dW, dbias, None, None, None, None, None
+        return dx, dW, dbias, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
-    return _Conv.apply(x, weight, bias, stride, pad, relu, False)
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, dest=None):
+    return _Conv.apply(x, weight, bias, stride, pad, relu, False, False, dest)
 
 
 def conv2d_with_stats(x, weight, stride=1, pad=0):
@@ -201,12 +250,13 @@ class _BatchNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale,
-                partial=None):
-        x = x.contiguous()
-        res_c = res.contiguous() if res is not None else None
+                partial=None, dest=None):
+        x = K.nhwc(x)
+        res_c = K.nhwc(res) if res is not None else None
         rs = float(res_scale) if res is not None else 1.0
+        out = dest[0].slice(dest[1], x.shape[3], x.shape[:3]) if dest is not None else None
         y, mean, invstd = K.bn_forward(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps,
-                                       training, relu, res_c, rs, partial=partial if training else None)
+                                       training, relu, res_c, rs, partial=partial if training else None, out=out)
         # without a residual the ReLU mask is a function of x alone: the backward recomputes it (mode 2)
         # instead of reading the saved output
         mode = 0 if not relu else (1 if res is not None else 2)
@@ -218,17 +268,17 @@ class _BatchNorm(torch.autograd.Function):
     def backward(ctx, dy):
         training, relu, rs, has_res = ctx.cfg
         x, y, gamma, beta, mean, invstd = ctx.saved_tensors
-        dx, dres, dgamma, dbeta = K.bn_backward(dy.contiguous(), y, x, gamma, mean, invstd, training, relu, rs,
+        dx, dres, dgamma, dbeta = K.bn_backward(K.nhwc(dy), y, x, gamma, mean, invstd, training, relu, rs,
                                                 want_dres=has_res and ctx.needs_input_grad[9], beta=beta)
         if has_res and ctx.needs_input_grad[9] and dres is None:
             dres = dy
-        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
 
 
 def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu=False, res=None, res_scale=1.0,
-               partial=None):
+               partial=None, dest=None):
     return _BatchNorm.apply(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu, res, res_scale,
-                            partial)
+                            partial, dest)
 
 
 def _gate_mlp(avg, mx, w1, w2):

@@ -32,9 +32,12 @@ class Generator(nn.Module):
 
     def features(self, dem, context):
         """dem, context: NHWC activations (engine.from_nchw)."""
-        d = self.convd2(self.convd1(dem))
-        f = self.convf2(self.convf1(context))
-        return self.block(self.conv(E.cat((d, f))))
+        B, H, W = context.shape[:3]
+        nd, nc = self.convd2.conv[0].out_channels, self.convf2.conv[0].out_channels
+        buf = E.SliceBuffer(B, H, W, nd + nc, context.dtype, context.device)  # cat((d, f)) without the copy
+        d = self.convd2(self.convd1(dem), dest=(buf, 0))
+        f = self.convf2(self.convf1(context), dest=(buf, nd))
+        return self.block(self.conv(buf.join((d, f))))
 
     def heads(self, feature):
         """NHWC weight (B,H,W,9) after the sigmoid and the 16 learned offset channels (B,H,W,16)."""
