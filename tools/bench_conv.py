@@ -39,7 +39,7 @@ def timeit(fn, n=10):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-    only = int(sys.argv[2]) if len(sys.argv) > 2 else None      # shape index
+    only = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) >= 0 else None      # shape index (-1: all)
     dts = (torch.bfloat16,) if len(sys.argv) > 3 and sys.argv[3] == "bf16" else (torch.float32, torch.bfloat16)
     ours_only = len(sys.argv) > 4
     for dtype in dts:
@@ -57,6 +57,10 @@ def main():
                 xc = x.permute(0, 3, 1, 2)  # channels_last view
                 wc = w.to(dtype).contiguous(memory_format=torch.channels_last)
                 tm = float("nan") if ours_only else timeit(lambda: F.conv2d(xc, wc, None, s, pad))
+            elif which == "wgrad":
+                go = torch.randn(B, OH, OW, Co, device="cuda").to(dtype)
+                t = timeit(lambda: K.conv2d_wgrad(go, x, Co, Ci, k, k, s, pad))
+                tm = float("nan")
             else:
                 go = torch.randn(B, OH, OW, Co, device="cuda").to(dtype)
                 wpt = K.pack_weight(w, 1, Co, dtype)
