@@ -16,29 +16,106 @@ from .ddp import GradReducer
 
 
 class FlatAdamW:
-    def __init__(self, reducer: GradReducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """lr_overrides: {parameter: lr} -- the reference's optional second parameter group (`diff_lr`: the
+    `postprocessor` parameters at lr 3e-4, utils/common_config.py:247-258).  Overridden parameters that are
+    neighbours in the flat buffer form one range; a step is one launch per range (2 for the reference's grouping).
+    `param_groups` mirrors torch's list of dicts ("lr", "initial_lr") so schedulers can drive it."""
+
+    def __init__(self, reducer: GradReducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 lr_overrides=None):
         self.reducer = reducer
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.flat_p = torch.empty_like(reducer.flat)
+        over = {id(p): float(v) for p, v in (lr_overrides or {}).items()}
+        self.param_groups = [{"lr": float(lr), "initial_lr": float(lr), "ranges": []}]
+        by_lr = {}
         off = 0
         for p in reversed(reducer.params):          # same order as the gradient buffer
             n = p.numel()
             self.flat_p[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + n].view_as(p)
+            if id(p) in over:
+                g = by_lr.get(over[id(p)])
+                if g is None:
+                    g = by_lr[over[id(p)]] = {"lr": over[id(p)], "initial_lr": over[id(p)], "ranges": []}
+                    self.param_groups.append(g)
+            else:
+                g = self.param_groups[0]
+            if g["ranges"] and g["ranges"][-1][1] == off:
+                g["ranges"][-1][1] = off + n
+            else:
+                g["ranges"].append([off, off + n])
             off += n
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.steps = 0
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, v):
+        self.param_groups[0]["lr"] = float(v)
 
     def step(self):
         if not self.flat_p.is_cuda:
             raise RuntimeError("FlatAdamW runs on the GPU only")
         self.steps += 1
         lib = _lib.load()
-        _lib.check(lib.jspsr_adamw_step(self.flat_p.data_ptr(), self.reducer.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                        self.exp_avg_sq.data_ptr(), self.flat_p.numel(), self.lr, self.betas[0],
-                                        self.betas[1], self.eps, self.weight_decay, self.steps,
-                                        torch.cuda.current_stream().cuda_stream), "jspsr_adamw_step")
+        stream = torch.cuda.current_stream().cuda_stream
+        es = self.flat_p.element_size()
+        for g in self.param_groups:
+            for lo, hi in g["ranges"]:
+                _lib.check(lib.jspsr_adamw_step(self.flat_p.data_ptr() + lo * es, self.reducer.flat.data_ptr() + lo * es,
+                                                self.exp_avg.data_ptr() + lo * es, self.exp_avg_sq.data_ptr() + lo * es,
+                                                hi - lo, g["lr"], self.betas[0], self.betas[1], self.eps,
+                                                self.weight_decay, self.steps, stream), "jspsr_adamw_step")
 
     def zero_grad(self):
         self.reducer.zero_grad()
+
+
+class WarmupStepLR:
+    """The reference's "warmupsteplr" schedule (utils/common_config.py:339-358): SequentialLR of
+    LambdaLR(1 / 10**(warmup_epoch - e)) for the first `warmup_epoch` epochs, then StepLR(step_size, gamma)
+    counted from the hand-over.  Closed form per epoch e (one `step()` per epoch, as train loops call it):
+
+        e <  warmup_epoch :  lr = initial_lr * 10**-(warmup_epoch - e)
+        e >= warmup_epoch :  lr = initial_lr * gamma**((e - warmup_epoch) // step_size)
+
+    Works on anything with torch-style `param_groups` (FlatAdamW, torch optimizers)."""
+
+    def __init__(self, optimizer, warmup_epoch=0, step_size=100, gamma=0.5):
+        self.optimizer = optimizer
+        self.warmup_epoch, self.step_size, self.gamma = int(warmup_epoch), int(step_size), float(gamma)
+        for g in optimizer.param_groups:
+            g.setdefault("initial_lr", g["lr"])
+        self.last_epoch = 0
+        self._apply()
+
+    def factor(self, epoch: int) -> float:
+        if epoch < self.warmup_epoch:
+            return 1.0 / (10.0 ** float(self.warmup_epoch - epoch))
+        if self.warmup_epoch == 0:  # SequentialLR never "reaches" a milestone at 0: StepLR then runs one epoch late
+            return self.gamma ** (max(epoch - 1, 0) // self.step_size)
+        return self.gamma ** ((epoch - self.warmup_epoch) // self.step_size)
+
+    def _apply(self):
+        f = self.factor(self.last_epoch)
+        for g in self.optimizer.param_groups:
+            g["lr"] = g["initial_lr"] * f
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = int(sd["last_epoch"])
+        self._apply()

@@ -62,3 +62,30 @@ def test_cabi_argument_validation_without_gpu():
     assert b"null" in lib.jspsr_last_error()
     assert lib.jspsr_prop_backward_workspace_bytes(8, 512, 512) == 4096 * 10 * 4  # 64x8 tiles
     assert lib.jspsr_prop_backward_workspace_bytes(0, 512, 512) == 0
+
+
+def test_warmup_step_lr_matches_the_reference_composition():
+    """utils/common_config.py:339-358 builds SequentialLR([LambdaLR(warmup), StepLR], [warmup_epoch]) on a torch
+    optimizer; the closed form must give the same learning rate every epoch, for both parameter groups."""
+    import warnings
+    import torch
+    from jspsr_amd.optim import WarmupStepLR
+
+    for warm, step_size, gamma, epochs in ((3, 100, 0.5, 320), (5, 7, 0.3, 40), (0, 4, 0.5, 14)):
+        w = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+        ropt = torch.optim.AdamW([{"params": [w[0]]}, {"params": [w[1]], "lr": 3e-4}], lr=1e-3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            train = torch.optim.lr_scheduler.StepLR(ropt, step_size=step_size, gamma=gamma)
+            warmup = torch.optim.lr_scheduler.LambdaLR(ropt, lr_lambda=lambda e, warm=warm: 1 / (10 ** float(warm - e)))
+            ref = torch.optim.lr_scheduler.SequentialLR(ropt, [warmup, train], [warm])
+
+            class Opt:
+                param_groups = [{"lr": 1e-3}, {"lr": 3e-4}]
+            mine = WarmupStepLR(Opt(), warm, step_size, gamma)
+            for e in range(epochs):
+                a, b = ref.get_last_lr(), mine.get_last_lr()
+                assert all(abs(x - y) <= 1e-12 * max(abs(x), 1e-30) + 1e-18 for x, y in zip(a, b)), (warm, e, a, b)
+                ropt.step()
+                ref.step()
+                mine.step()

@@ -47,3 +47,35 @@ def test_flat_adamw_matches_torch():
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     assert set(net.state_dict()) == set(ref.state_dict())
+
+
+def test_flat_adamw_second_lr_group_and_schedule():
+    """diff_lr grouping of utils/common_config.py:247-258 (named parameters containing a key run at their own
+    learning rate) + the WarmupStepLR schedule, against torch.optim.AdamW with two param groups."""
+    from jspsr_amd.ddp import GradReducer
+    from jspsr_amd.optim import FlatAdamW, WarmupStepLR
+    torch.manual_seed(1)
+    mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.Conv2d(8, 8, 1), torch.nn.Conv2d(8, 5, 1)).cuda()
+    net, ref = mk(), mk()
+    ref.load_state_dict(net.state_dict())
+    red = GradReducer(net.parameters())
+    opt = FlatAdamW(red, lr=1e-3, weight_decay=1e-6, lr_overrides={p: 3e-4 for p in net[1].parameters()})
+    assert len(opt.param_groups) == 2 and sum(len(g["ranges"]) for g in opt.param_groups) == 3
+    ropt = torch.optim.AdamW([{"params": list(ref[0].parameters()) + list(ref[2].parameters())},
+                              {"params": list(ref[1].parameters()), "lr": 3e-4}], lr=1e-3, weight_decay=1e-6)
+    sch = WarmupStepLR(opt, warmup_epoch=2, step_size=2, gamma=0.5)
+    rsch = WarmupStepLR(ropt, warmup_epoch=2, step_size=2, gamma=0.5)
+    x = torch.randn(4, 3, 9, 9, device="cuda")
+    for _ in range(6):
+        opt.zero_grad()
+        net(x).square().mean().backward()
+        red.finish()
+        opt.step()
+        sch.step()
+        ropt.zero_grad()
+        ref(x).square().mean().backward()
+        ropt.step()
+        rsch.step()
+        assert sch.get_last_lr() == rsch.get_last_lr()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
