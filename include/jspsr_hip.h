@@ -190,7 +190,8 @@ int jspsr_loss_backward(const float* pred, const float* gt, const float* grad_to
                         jspsr_stream_t stream);
 
 /* One AdamW step (torch.optim.AdamW semantics: decoupled weight decay, bias correction) over a flat
- * fp32 parameter / gradient / moment buffer of n elements (utils/common_config.py:241-291). */
+ * fp32 parameter / gradient / moment buffer of n elements (utils/common_config.py:241-291).  The four pointers are
+ * 4-byte aligned and share one offset from a 16-byte boundary (sub-ranges of four identically laid out buffers). */
 int jspsr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, jspsr_stream_t stream);
 

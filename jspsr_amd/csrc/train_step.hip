@@ -118,33 +118,46 @@ __global__ __launch_bounds__(LT) void loss_bwd_kernel(const float* __restrict__ 
 }
 
 // AdamW, decoupled weight decay, bias-corrected (torch.optim.AdamW, maximize=False, amsgrad=False)
+__device__ __forceinline__ void adamw_one(float& P, float G, float& M, float& V, float lr, float beta1, float beta2,
+                                          float eps, float wd, float bc1, float bc2s) {
+  P *= 1.f - lr * wd;
+  M = beta1 * M + (1.f - beta1) * G;
+  V = beta2 * V + (1.f - beta2) * G * G;
+  P -= (lr / bc1) * M / (sqrtf(V) / bc2s + eps);
+}
+
+// `head` scalar elements bring the four (equally misaligned) buffers to a 16-byte boundary, then float4s, then a tail.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long long n, float lr,
-                                                   float beta1, float beta2, float eps, float wd, float bc1, float bc2s) {
-  const long long n4 = n / 4;
+                                                   float* __restrict__ m, float* __restrict__ v, long long n, int head,
+                                                   float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                   float bc2s) {
+  const long long n4 = (n - head) / 4;
+  float4* p4 = reinterpret_cast<float4*>(p + head);
+  const float4* g4 = reinterpret_cast<const float4*>(g + head);
+  float4* m4 = reinterpret_cast<float4*>(m + head);
+  float4* v4 = reinterpret_cast<float4*>(v + head);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    float4 P = reinterpret_cast<float4*>(p)[i];
-    const float4 G = reinterpret_cast<const float4*>(g)[i];
-    float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
-    float* pp = &P.x; const float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      pp[k] *= 1.f - lr * wd;
-      mm[k] = beta1 * mm[k] + (1.f - beta1) * gg[k];
-      vv[k] = beta2 * vv[k] + (1.f - beta2) * gg[k] * gg[k];
-      pp[k] -= (lr / bc1) * mm[k] / (sqrtf(vv[k]) / bc2s + eps);
-    }
-    reinterpret_cast<float4*>(p)[i] = P;
-    reinterpret_cast<float4*>(m)[i] = M;
-    reinterpret_cast<float4*>(v)[i] = V;
+    float4 P = p4[i];
+    const float4 G = g4[i];
+    float4 M = m4[i], V = v4[i];
+    adamw_one(P.x, G.x, M.x, V.x, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    adamw_one(P.y, G.y, M.y, V.y, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    adamw_one(P.z, G.z, M.z, V.z, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    adamw_one(P.w, G.w, M.w, V.w, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    p4[i] = P;
+    m4[i] = M;
+    v4[i] = V;
   }
-  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
-    const long long i = n4 * 4 + threadIdx.x;
-    float P = p[i] * (1.f - lr * wd);
-    const float M = beta1 * m[i] + (1.f - beta1) * g[i];
-    const float V = beta2 * v[i] + (1.f - beta2) * g[i] * g[i];
-    P -= (lr / bc1) * M / (sqrtf(V) / bc2s + eps);
-    p[i] = P; m[i] = M; v[i] = V;
+  if (blockIdx.x == 0 && threadIdx.x < 8) {  // up to 3 head + 3 tail elements
+    const int tail = (int)(n - head - n4 * 4);
+    long long i = -1;
+    if ((int)threadIdx.x < head) i = threadIdx.x;
+    else if ((int)threadIdx.x >= 4 && (int)threadIdx.x - 4 < tail) i = head + n4 * 4 + (threadIdx.x - 4);
+    if (i >= 0) {
+      float P = p[i], M = m[i], V = v[i];
+      adamw_one(P, g[i], M, V, lr, beta1, beta2, eps, wd, bc1, bc2s);
+      p[i] = P; m[i] = M; v[i] = V;
+    }
   }
 }
 
@@ -190,13 +203,17 @@ extern "C" int jspsr_loss_backward(const float* pred, const float* gt, const flo
 extern "C" int jspsr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, int step, jspsr_stream_t stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return fail(JSPSR_EINVAL, "adamw_step: bad arguments");
-  if (!aligned16(param) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
-    return fail(JSPSR_EALIGN, "adamw_step: buffers must be 16-byte aligned");
+  const uintptr_t mis = reinterpret_cast<uintptr_t>(param) & 15;
+  if ((mis & 3) || (reinterpret_cast<uintptr_t>(grad) & 15) != mis || (reinterpret_cast<uintptr_t>(exp_avg) & 15) != mis ||
+      (reinterpret_cast<uintptr_t>(exp_avg_sq) & 15) != mis)
+    return fail(JSPSR_EALIGN, "adamw_step: buffers must be 4-byte aligned and equally offset from a 16-byte boundary");
+  int head = (int)(((16 - mis) & 15) >> 2);
+  if (head > n) head = (int)n;
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   long long b = (n / 4 + 255) / 256;
   const int blocks = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg,
-                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                     exp_avg_sq, n, head, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
   return check_launch("adamw_step");
 }
