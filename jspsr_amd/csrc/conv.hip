@@ -42,7 +42,7 @@ __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
 template <int MI, int NI, int WGM, int WTM, int WTN, int BN, typename OutPix>
 __device__ __forceinline__ void stats_epilogue(const f32x16 (&acc)[MI][NI], float* __restrict__ stats, char* scratch,
                                                int tile, int Cout, int n0, int wm, int wn, int lr, int lh,
-                                               OutPix&& out_pixel) {
+                                               OutPix&& out_pixel, int zero_tile = -1) {
   float* red = reinterpret_cast<float*>(scratch);   // [WGM][2][BN]
   float s[NI], q[NI];
 #pragma unroll
@@ -77,6 +77,7 @@ __device__ __forceinline__ void stats_epilogue(const f32x16 (&acc)[MI][NI], floa
 #pragma unroll
     for (int w = 0; w < WGM; ++w) t += red[(w * 2 + which) * BN + col];
     stats[((size_t)tile * 2 + which) * Cout + n0 + col] = t;
+    if (zero_tile >= 0) stats[((size_t)zero_tile * 2 + which) * Cout + n0 + col] = 0.f;  // row of a tile folded into `tile`
   }
   __syncthreads();
 }
@@ -367,6 +368,8 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
   }
 }
 
+__host__ __device__ constexpr int patch_it(int BM) { return ((BM / 16 + 2) * 18 * NCH + NT - 1) / NT; }
+
 // ---------------------------------------------------------------------------------------------
 // Patch variant for unit-stride tap walks (forward stride-1 convs, every data-gradient /
 // transposed-conv phase) with Cin a multiple of the stage depth.  The implicit-GEMM kernel above
@@ -376,17 +379,17 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
 // tile still streams per tap (two-deep register prefetch).  The next chunk's patch is prefetched
 // into registers at the first tap of the current chunk and written at its last.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                           float* __restrict__ stats, ConvGeom g) {
   static_assert(WGM * WGN == 4, "4 waves");
-  constexpr int BM = 128, TLW = 16, TLH = BM / TLW;
+  constexpr int TLW = 16, TLH = BM / TLW;
   constexpr int EPC = Elem<T>::EPC, BK = NCH * EPC;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
   constexpr int B_IT = (BN * NCH + NT - 1) / NT;
-  constexpr int P_IT = 6;                    // patch chunks per thread: (8+2)*(16+2) pixels * 8 chunks <= 6 * 256
-  constexpr int MAXPIX = P_IT * NT / NCH;    // 192 patch pixels
+  constexpr int P_IT = patch_it(BM);         // patch chunks per thread: (TLH+2)*(16+2) pixels * 8 chunks <= P_IT * 256
+  constexpr int MAXPIX = P_IT * NT / NCH;    // 192 (8x16 tile) / 352 (16x16 tile) patch pixels
   constexpr int BS_BYTES = BN * ROWB;
   constexpr unsigned OOB = 0xFFFFFFF0u;
   using frag_t = typename Frag<T>::type;
@@ -510,17 +513,31 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
     constexpr int buf = decltype(BUF)::value;
     const int oy = g.sign > 0 ? cty : g.nty - 1 - cty, ox = g.sign > 0 ? ctx : g.ntx - 1 - ctx;
     const int tapoff = (oy * PW + ox) * ROWB;
+    // fragments of sub-step s+1 are requested before the MFMAs of sub-step s are issued, so an LDS read has a
+    // whole sub-step of matrix work to land in (the scheduler, left alone, places each read right before its use)
+    frag_t a[2][MI], b[2][NI];
+    auto frags = [&](int set, int s) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[set][mi] = *reinterpret_cast<const frag_t*>(Ps + a_ld[mi] + tapoff + s * 32);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[set][ni] = *reinterpret_cast<const frag_t*>(b_ld + buf * BS_BYTES + ni * 32 * ROWB + s * 32);
+    };
+    frags(0, 0);
 #pragma unroll
     for (int s = 0; s < NCH / 2; ++s) {
-      frag_t a[MI], b[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag_t*>(Ps + a_ld[mi] + tapoff + s * 32);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const frag_t*>(b_ld + buf * BS_BYTES + ni * 32 * ROWB + s * 32);
+      if (s + 1 < NCH / 2) frags((s + 1) & 1, s + 1);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) mma_chunk(acc[mi][ni], a[mi], b[ni]);
+        for (int ni = 0; ni < NI; ++ni) mma_chunk(acc[mi][ni], a[s & 1][mi], b[s & 1][ni]);
+    }
+    // pin the order: reads(0) reads(1) mfma(0) reads(2) mfma(1) reads(3) mfma(2) mfma(3)
+    constexpr int NR = MI + NI, NM = MI * NI * (sizeof(T) == 4 ? 4 : 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+    for (int s = 0; s < NCH / 2; ++s) {
+      if (s + 1 < NCH / 2) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
     }
   };
   auto step = [&](auto CUR, auto NXT) {
@@ -558,7 +575,18 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
     const int oy = y * g.oy_mul + g.oy_add, ox = x * g.ox_mul + g.ox_add;
     return (y < g.MH && x < g.MW && oy < g.OH && ox < g.OW) ? ((long long)bimg * g.OH + oy) * g.OW + ox : -1;
   };
-  if (stats) stats_epilogue<MI, NI, WGM, WTM, WTN, BN>(acc, stats, smem, mt, g.Cout, n0, wm, wn, lr, lh, out_pixel);
+  if (stats) {
+    // partial rows are numbered by 8x16-pixel tiles (jspsr_conv2d_stats_rows); a 16x16 tile reports under its
+    // upper half's number and zeroes the lower half's row
+    if constexpr (BM == 128) {
+      stats_epilogue<MI, NI, WGM, WTM, WTN, BN>(acc, stats, smem, mt, g.Cout, n0, wm, wn, lr, lh, out_pixel);
+    } else {
+      const int tty8 = (g.MH + 7) / 8;
+      const int r1 = (bimg * tty8 + 2 * tyi) * ttx + txi;
+      const int r2 = (2 * tyi + 1 < tty8) ? r1 + ttx : -1;
+      stats_epilogue<MI, NI, WGM, WTM, WTN, BN>(acc, stats, smem, r1, g.Cout, n0, wm, wn, lr, lh, out_pixel, r2);
+    }
+  }
   float bv[NI];
   int ncol[NI];
 #pragma unroll
@@ -614,14 +642,14 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int BN, int WGM, int WGN>
+template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_patch(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
-  constexpr int BM = 128, TLW = 16, TLH = BM / TLW, MAXPIX = 6 * NT / NCH;
+  constexpr int TLW = 16, TLH = BM / TLW, MAXPIX = patch_it(BM) * NT / NCH;
   const long long nblk = (long long)g.B * ((g.MH + TLH - 1) / TLH) * ((g.MW + TLW - 1) / TLW) * ((g.Cout + BN - 1) / BN);
   if (nblk > 0x7fffffffLL) return fail(JSPSR_EINVAL, "conv: grid too large");
   const size_t lds_stage = (size_t)MAXPIX * ROWB + 2 * BN * ROWB, lds_out = (size_t)BM * (BN * sizeof(T) + 16);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
-  auto kern = conv_patch_kernel<T, BN, WGM, WGN>;
+  auto kern = conv_patch_kernel<T, BM, BN, WGM, WGN>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -668,9 +696,16 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
   constexpr int BKT = NCH * Elem<T>::EPC;
   if (!no_patch && g.iy_mul == 1 && g.ix_mul == 1 && g.nty >= 1 && g.ntx >= 1 && g.nty <= 3 && g.ntx <= 3 &&
       g.nty * g.ntx > 1 && g.Cin % BKT == 0 && (long long)(g.IW + 20) * 12 * g.in_cstride * (long long)sizeof(T) < 0xE0000000LL) {
-    if (g.Cout > 64) return launch_patch<T, 128, 2, 2>(in, wgt, bias, out, stats, g, s);
-    if (g.Cout > 32) return launch_patch<T, 64, 2, 2>(in, wgt, bias, out, stats, g, s);
-    return launch_patch<T, 32, 4, 1>(in, wgt, bias, out, stats, g, s);
+    if (g.Cout > 64) return launch_patch<T, 128, 128, 2, 2>(in, wgt, bias, out, stats, g, s);
+    if (g.Cout > 32) {
+      // 64 output channels: a 16x16-pixel tile (4 waves x 64 px x 64 ch) halves the weight-tile staging and the
+      // fragment reads per MFMA of the 8x16 tile; worth it once the image has enough tiles to fill the chip
+      static const int tall = [] { const char* e = getenv("JSPSR_CONV_TALL"); return e ? atoi(e) : 1; }();
+      const long long tiles16 = (long long)g.B * ((g.MH + 15) / 16) * ((g.MW + 15) / 16);
+      if (tall && tiles16 >= 1024) return launch_patch<T, 256, 64, 4, 1>(in, wgt, bias, out, stats, g, s);
+      return launch_patch<T, 128, 64, 2, 2>(in, wgt, bias, out, stats, g, s);
+    }
+    return launch_patch<T, 128, 32, 4, 1>(in, wgt, bias, out, stats, g, s);
   }
   static const int nbuf_env = [] { const char* e = getenv("JSPSR_CONV_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf_narrow = nbuf_env ? nbuf_env : ((long long)g.nty * g.ntx * g.Cin <= 1152 ? 1 : 2);

@@ -261,6 +261,243 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 layers (every residual-block conv): all nine taps from one staging.
+//
+// A workgroup owns a 64-channel tile of G, a 64-channel chunk of X and a column strip of the image (U output
+// pixels wide) over a range of rows, and walks down the strip one output row per step.  Per step it stages the
+// G row segment (U px) and ONE new X row segment (U + 2 px, with the left/right neighbours); the previous two X
+// rows are still in a 4-slot LDS ring.  The nine taps are nine MFMA accumulators fed from the same G fragment
+// and nine shifted views of the ring (ky = ring slot, kx = +0/1/2 pixel rows in LDS), so each operand element
+// is loaded from memory and stored to LDS once per (G tile, X chunk) instead of once per tap: 3.3x fewer
+// staging bytes than the generic kernel above, whose main loop is bound by the VGPR->LDS store path.
+// Slabs have the generic kernel's [G channel][tap*Cx + c] layout and go through the same ordered reduce.
+// ---------------------------------------------------------------------------------------------
+struct PatchGeom {
+  int B, H, W;              // output grid == input grid
+  int Cg, g_cs, g_coff;
+  int Cx, x_cs, x_coff;
+  int Ktot;                 // 9 * Cx
+  int strips_x;             // W / U
+  int rows_per_blk, row_blks;
+  int pairs_g, pairs_x;     // tiles of G channels / chunks of X channels
+};
+
+template <typename T> struct WP;
+template <> struct WP<float> { static constexpr int U = 32; };
+template <> struct WP<__bf16> { static constexpr int U = 64; };
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict__ G, const T* __restrict__ X,
+                                                           float* __restrict__ ws, PatchGeom g) {
+  constexpr int EPC = WT<T>::EPC, U = WP<T>::U, TC = 64;      // 64-channel tiles on both sides
+  constexpr int P = pitch_bytes(TC * sizeof(T));               // LDS bytes per pixel row
+  constexpr int CPR = TC / EPC;                                // 16-byte chunks per pixel row
+  constexpr int G_IT = U * CPR / NT, X_IT = ((U + 2) * CPR + NT - 1) / NT, RSTEP = NT / CPR;
+  constexpr int GS_BYTES = U * P, XS_BYTES = (U + 2) * P;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  static_assert(U * CPR % NT == 0 && NT % CPR == 0, "tile");
+  __shared__ __attribute__((aligned(16))) char Gs[2 * GS_BYTES];
+  __shared__ __attribute__((aligned(16))) char Xs[4 * XS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int npair = g.pairs_g * g.pairs_x;
+  const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int pair = lin % npair, unit = lin / npair;            // the pairs of one unit share its G / X rows in L2
+  const int pg = pair % g.pairs_g, px = pair / g.pairs_g;
+  const int rb = unit % g.row_blks, strip = unit / g.row_blks;
+  const int sx = strip % g.strips_x, b = strip / g.strips_x;
+  const int co0 = pg * TC, cx0 = px * TC, ox0 = sx * U;
+  const int y0 = rb * g.rows_per_blk;
+  const int y1 = (y0 + g.rows_per_blk < g.H) ? y0 + g.rows_per_blk : g.H;
+
+  // descriptors: one image each; voffset = (row*W + col) * pitch + channel, anything outside -> OOB -> zeros
+  const int g_pix = g.g_cs * (int)sizeof(T), x_pix = g.x_cs * (int)sizeof(T);
+  const char* gbase = reinterpret_cast<const char*>(G) + ((size_t)b * g.H * g.W * g.g_cs + g.g_coff) * sizeof(T);
+  const char* xbase = reinterpret_cast<const char*>(X) + ((size_t)b * g.H * g.W * g.x_cs + g.x_coff) * sizeof(T);
+  const unsigned g_range = (unsigned)((long long)g.H * g.W * g_pix), x_range = (unsigned)((long long)g.H * g.W * x_pix);
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gbase), 0, g_range, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, x_range, 0x00020000);
+
+  const int ch = tid % CPR, r0 = tid / CPR;                    // this thread's chunk column and first pixel
+  const bool g_ok = co0 + ch * EPC < g.Cg, x_ok = cx0 + ch * EPC < g.Cx;
+  unsigned gcol[G_IT], xcol[X_IT];                             // byte offset of (pixel in row, channel), or OOB
+#pragma unroll
+  for (int i = 0; i < G_IT; ++i)
+    gcol[i] = g_ok ? (unsigned)((ox0 + r0 + i * RSTEP) * g_pix + (co0 + ch * EPC) * (int)sizeof(T)) : OOB;
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int j = r0 + i * RSTEP, ix = ox0 - 1 + j;            // LDS pixel j holds input column ox0 - 1 + j
+    xcol[i] = (x_ok && j < U + 2 && (unsigned)ix < (unsigned)g.W)
+                  ? (unsigned)(ix * x_pix + (cx0 + ch * EPC) * (int)sizeof(T)) : OOB;
+  }
+  const unsigned g_rowb = (unsigned)(g.W * g_pix), x_rowb = (unsigned)(g.W * x_pix);
+
+  uint4 greg[2][G_IT], xreg[2][X_IT];
+  auto load_g = [&](auto SET, int oy) {
+    constexpr int set = decltype(SET)::value;
+    const bool ok = oy < y1;                                   // uniform
+#pragma unroll
+    for (int i = 0; i < G_IT; ++i) {
+      const unsigned off = (ok && gcol[i] != OOB) ? gcol[i] + (unsigned)oy * g_rowb : OOB;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(grsrc, off, 0, 0);
+      greg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto load_x = [&](auto SET, int iy) {
+    constexpr int set = decltype(SET)::value;
+    const bool ok = (unsigned)iy < (unsigned)g.H;              // uniform: rows above / below the raster are zeros
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const unsigned off = (ok && xcol[i] != OOB) ? xcol[i] + (unsigned)iy * x_rowb : OOB;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+      xreg[set][i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  char* const g_st = Gs + r0 * P + ch * 16;
+  char* const x_st = Xs + r0 * P + ch * 16;
+  auto store_g = [&](auto SET, int buf) {
+    constexpr int set = decltype(SET)::value;
+#pragma unroll
+    for (int i = 0; i < G_IT; ++i) *reinterpret_cast<uint4*>(g_st + buf * GS_BYTES + i * RSTEP * P) = greg[set][i];
+  };
+  auto store_x = [&](auto SET, int slot) {
+    constexpr int set = decltype(SET)::value;
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i)
+      if ((X_IT * RSTEP <= U + 2) || r0 + i * RSTEP < U + 2)
+        *reinterpret_cast<uint4*>(x_st + slot * XS_BYTES + i * RSTEP * P) = xreg[set][i];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;                     // 2 x 2 waves of 32 x 32 per tap
+  const int lr = lane & 31, lh = lane >> 5;
+  const int grp16 = (lane >> 4) & 1, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int g_ld = sizeof(T) == 4 ? lh * P + (wm * 32 + lr) * 4 : (8 * lh + q) * P + (wm * 32 + 16 * grp16 + 4 * pp) * 2;
+  const int x_ld = sizeof(T) == 4 ? lh * P + (wn * 32 + lr) * 4 : (8 * lh + q) * P + (wn * 32 + 16 * grp16 + 4 * pp) * 2;
+
+  // one output row: G buffer `gbuf`, X rows iy = oy-1, oy, oy+1 in ring slots (oy + ky) & 3
+  auto compute = [&](int gbuf, int oy) {
+    const char* gp = Gs + gbuf * GS_BYTES + g_ld;
+    const char* xp[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) xp[ky] = Xs + ((oy + ky) & 3) * XS_BYTES + x_ld;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll 2
+      for (int s2 = 0; s2 < U / 2; ++s2) {
+        const float a = *reinterpret_cast<const float*>(gp + 2 * s2 * P);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float bv = *reinterpret_cast<const float*>(xp[ky] + (2 * s2 + kx) * P);
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ky * 3 + kx], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < U / 16; ++kb) {
+        const char* pa = gp + kb * 16 * P;
+        const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+        const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 4 * P));
+        const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const char* pb = xp[ky] + (kb * 16 + kx) * P;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * P));
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[ky * 3 + kx], 0, 0, 0);
+          }
+      }
+    }
+  };
+
+  // prologue: X rows y0-1 and y0 straight into the ring, then the two-deep register pipeline of
+  // (G row oy, X row oy+1) pairs.  Steps are branch-free (rows past the range load as zeros, unused).
+  load_x(S0{}, y0 - 1);
+  load_x(S1{}, y0);
+  store_x(S0{}, (y0 + 0) & 3);
+  store_x(S1{}, (y0 + 1) & 3);
+  load_g(S0{}, y0);
+  load_x(S0{}, y0 + 1);
+  load_g(S1{}, y0 + 1);
+  load_x(S1{}, y0 + 2);
+  store_g(S0{}, 0);
+  store_x(S0{}, (y0 + 2) & 3);
+  __syncthreads();
+  // step for row oy (stage parity CUR): loads of row oy+2 -> MFMAs of row oy -> row oy+1 regs -> LDS -> barrier
+  auto step = [&](auto CUR, auto NXT, int oy) {
+    constexpr int cur = decltype(CUR)::value;
+    load_g(CUR, oy + 2);
+    load_x(CUR, oy + 3);
+    compute(cur, oy);
+    store_g(NXT, cur ^ 1);
+    store_x(NXT, (oy + 3) & 3);
+    __syncthreads();
+  };
+  int oy = y0;
+  for (; oy + 1 < y1; oy += 2) {
+    step(S0{}, S1{}, oy);
+    step(S1{}, S0{}, oy + 1);
+  }
+  if (oy < y1) step(S0{}, S1{}, oy);
+
+  float* slab = ws + (size_t)unit * g.Cg * g.Ktot;
+  const int c = cx0 + wn * 32 + lr;
+  if (c < g.Cx) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (co < g.Cg) slab[(size_t)co * g.Ktot + t * g.Cx + c] = acc[t][e];
+      }
+  }
+}
+
+struct PatchPlan {
+  bool ok;
+  int rows_per_blk, row_blks, units;
+};
+
+// Units (strip x row range) per (G tile, X chunk) pair: enough workgroups to fill the chip twice over, but rows
+// per workgroup >= 8 so the two halo rows stay a small part of the staging.
+template <typename T>
+PatchPlan make_patch_plan(int B, int H, int W, int Cg, int Cx) {
+  PatchPlan p{};
+  constexpr int U = WP<T>::U;
+  if (W % U || Cg < 32 || Cx < 32) return p;
+  const long long pairs = (long long)((Cg + 63) / 64) * ((Cx + 63) / 64);
+  const long long strips = (long long)B * (W / U);
+  long long want = (640 + pairs * strips - 1) / (pairs * strips);   // row blocks per strip
+  if (want < 1) want = 1;
+  int rows = (int)((H + want - 1) / want);
+  if (rows < 8) rows = H < 8 ? H : 8;
+  p.rows_per_blk = rows;
+  p.row_blks = (H + rows - 1) / rows;
+  const long long units = strips * p.row_blks;
+  if (units * pairs > 0x7fffffffLL || units > 0x7fffffffLL) return p;
+  p.units = (int)units;
+  p.ok = true;
+  return p;
+}
+
+bool wgrad_patch_enabled() {
+  static const bool on = [] { const char* e = getenv("JSPSR_WGRAD_NOPATCH"); return !(e && atoi(e)); }();
+  return on;
+}
+
 // dW[r][c][ky][kx] (+)= sum_z ws[z][r][(ky*KW+kx)*Cx + c],  r < R, c < C  (fixed summation order).
 // A (32 x 8)-thread workgroup owns 32 consecutive slab elements (128-byte coalesced reads of every
 // slab); its 8 z-lanes each sum every 8th slab, then fold in a fixed order.  The scattered 4-byte
@@ -333,6 +570,29 @@ int launch_w(const void* G, const void* X, float* ws, const WgradGeom& g, int sp
 
 template <typename T>
 int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradGeom& g, int accumulate, hipStream_t s) {
+  if (g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && g.IH == g.OH && g.IW == g.OW && wgrad_patch_enabled()) {
+    const PatchPlan pp = make_patch_plan<T>(g.B, g.OH, g.OW, g.Cg, g.Cx);
+    const long long img_g = (long long)g.OH * g.OW * g.g_cs * (long long)sizeof(T);
+    const long long img_x = (long long)g.IH * g.IW * g.x_cs * (long long)sizeof(T);
+    if (pp.ok && img_g < 0xF0000000LL && img_x < 0xF0000000LL) {
+      PatchGeom q{};
+      q.B = g.B; q.H = g.OH; q.W = g.OW;
+      q.Cg = g.Cg; q.g_cs = g.g_cs; q.g_coff = g.g_coff;
+      q.Cx = g.Cx; q.x_cs = g.x_cs; q.x_coff = g.x_coff;
+      q.Ktot = g.Ktot; q.strips_x = g.OW / WP<T>::U;
+      q.rows_per_blk = pp.rows_per_blk; q.row_blks = pp.row_blks;
+      q.pairs_g = (g.Cg + 63) / 64; q.pairs_x = (g.Cx + 63) / 64;
+      const long long nblk = (long long)pp.units * q.pairs_g * q.pairs_x;
+      hipLaunchKernelGGL(wgrad_patch_kernel<T>, dim3((unsigned)nblk), dim3(NT), 0, s, static_cast<const T*>(G),
+                         static_cast<const T*>(X), ws, q);
+      if (int e = check_launch("conv2d_wgrad_patch")) return e;
+      const long long total = (long long)R * g.Ktot;
+      const int blocks = (int)((total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dW, R, C, g.KH, g.KW, g.Cg, g.Cx,
+                         pp.units, accumulate);
+      return check_launch("conv2d_wgrad_reduce");
+    }
+  }
   const Plan p = make_plan<T>(g.M, g.Cg, g.Ktot);
   g.m_per_split = p.m_per_split;
   // 32-bit buffer offsets: one slice of G, and the images of X one slice touches, must stay < 3.75 GiB
@@ -360,7 +620,12 @@ extern "C" size_t jspsr_conv2d_wgrad_workspace_bytes(int dtype, int B, int OH, i
   const long long M = (long long)B * OH * OW;
   const int Ktot = KH * KW * Cx;
   const Plan p = dtype == JSPSR_BF16 ? make_plan<__bf16>(M, Cg, Ktot) : make_plan<float>(M, Cg, Ktot);
-  return (size_t)p.splits * Cg * Ktot * sizeof(float);
+  size_t splits = (size_t)p.splits;
+  if (KH == 3 && KW == 3) {  // the 3x3 stride-1 path slices differently (the caller's stride is not known here)
+    const PatchPlan pp = dtype == JSPSR_BF16 ? make_patch_plan<__bf16>(B, OH, OW, Cg, Cx) : make_patch_plan<float>(B, OH, OW, Cg, Cx);
+    if (pp.ok && (size_t)pp.units > splits) splits = (size_t)pp.units;
+  }
+  return splits * Cg * Ktot * sizeof(float);
 }
 
 extern "C" int jspsr_conv2d_wgrad(int dtype, const void* G, int Cg, int g_cstride, int g_coff, const void* X, int Cx,

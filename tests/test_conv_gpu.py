@@ -108,6 +108,85 @@ def test_conv_wgrad(dtype, B, H, W, Cin, Cout, k, stride, pad):
     assert _relerr(dW.cpu(), w.grad) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 256, 256, 64, 64), (5, 232, 250, 128, 40)])
+def test_conv_16x16_tile_path(dtype, B, H, W, Cin, Cout):
+    """Layers with 33..64 output channels on rasters of >= 1024 16x16-pixel tiles take the tall-tile
+    instantiation of the patch kernel (conv.hip: launch<T>): forward + BN partial statistics, ragged bottom/right
+    tiles and an odd count of 8-row tile bands (statistics rows are numbered by 8x16 tiles), and the data
+    gradient of a conv whose INPUT has that many channels."""
+    K = _k()
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    wp = K.pack_weight(w.cuda(), 0, Cin, dtype)
+    y, st = K.conv2d_forward(_nhwc(x).to(dtype), wp, None, 1, 1, stats=True)
+    tol = 2e-6 if dtype == torch.float32 else 6e-3
+    assert _relerr(_nchw(y.float()), ref) < tol
+    # statistics come from the fp32 accumulators (before rounding to the storage type)
+    tot = st.double().sum(0).cpu()
+    assert _relerr(tot[0], ref.sum((0, 2, 3))) < 1e-4 and _relerr(tot[1], (ref * ref).sum((0, 2, 3))) < 1e-5
+    # data gradient: gathered tensor has Cout channels, written tensor Cin -> swap roles so the WRITTEN side is <= 64
+    e = K.epc(dtype)
+    Cg = (Cin + e - 1) // e * e
+    w2 = torch.randn(Cin, Cout, 3, 3, generator=g) / (Cin * 9) ** 0.5   # conv Cout -> Cin; its dgrad writes Cout channels
+    go = torch.randn(B, Cin, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        go, w2 = go.bfloat16().float(), w2.bfloat16().float()
+    xx = torch.zeros(B, Cout, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xx, w2.double(), None, 1, 1).backward(go.double())
+    dx = K.conv2d_dgrad(_nhwc(F.pad(go, (0, 0, 0, 0, 0, Cg - Cin))).to(dtype), K.pack_weight(w2.cuda(), 1, Cg, dtype), (H, W), 1, 1)
+    assert _relerr(_nchw(dx.float()), xx.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (2, 64, 64, 64, 64),      # one tile pair
+    (1, 23, 128, 128, 64),    # odd row count, two X chunks
+    (3, 9, 64, 96, 160),      # channel tails on both sides (96 = 64 + 32, 160 = 2*64 + 32)
+    (1, 5, 192, 40, 72),      # fewer rows than a row block, ragged channels
+    (2, 128, 128, 64, 128),   # many row blocks per strip
+])
+def test_conv_wgrad_3x3_all_taps_path(dtype, B, H, W, Cin, Cout):
+    """The 3x3 / stride-1 layers take the nine-taps-per-staging kernel (wgrad.hip: wgrad_patch_kernel) when the
+    width is a multiple of its strip (64 px bf16, 32 px fp32); same oracle and tolerance as the generic kernel,
+    plus exact agreement with the generic kernel's slab layout through the shared ordered reduce."""
+    K = _k()
+    g = torch.Generator().manual_seed(B * 7 + H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    go = torch.randn(B, Cout, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x, go = x.bfloat16().float(), go.bfloat16().float()
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(go.double())
+    dW = K.conv2d_wgrad(_nhwc(go).to(dtype), _nhwc(x).to(dtype), Cout, Cin, 3, 3, 1, 1)
+    tol = 3e-6 if dtype == torch.float32 else 1e-5
+    assert _relerr(dW.cpu(), w.grad) < tol
+    # border taps in isolation: the corner weight gradient sees the zero padding on two sides
+    assert _relerr(dW.cpu()[:, :, 0, 0], w.grad[:, :, 0, 0]) < 10 * tol
+    assert _relerr(dW.cpu()[:, :, 2, 2], w.grad[:, :, 2, 2]) < 10 * tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_wgrad_3x3_channel_slices(dtype):
+    """Operands that are channel slices of wider buffers (pitch != channels), as the slice buffers hand them over."""
+    K = _k()
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 16, 64
+    xw = torch.randn(B, 192, H, W, generator=g)
+    gw = torch.randn(B, 160, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        xw, gw = xw.bfloat16().float(), gw.bfloat16().float()
+    w = torch.zeros(64, 64, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xw[:, 64:128].double(), w, None, 1, 1).backward(gw[:, 32:96].double())
+    Xd, Gd = _nhwc(xw).to(dtype), _nhwc(gw).to(dtype)
+    dW = K.conv2d_wgrad(Gd.narrow(3, 32, 64), Xd.narrow(3, 64, 64), 64, 64, 3, 3, 1, 1)
+    assert _relerr(dW.cpu(), w.grad) < (3e-6 if dtype == torch.float32 else 1e-5)
+
+
 def test_conv_transpose_wgrad():
     """ConvTranspose2d weight (I,O,kh,kw): G = its input, X = grad of its output."""
     K = _k()
