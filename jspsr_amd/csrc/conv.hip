@@ -70,7 +70,7 @@ __device__ __forceinline__ void stats_epilogue(const f32x16 (&acc)[MI][NI], floa
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * BN; i += NT) {
+  for (int i = threadIdx.x; i < 2 * BN; i += blockDim.x) {
     const int which = i / BN, col = i % BN;
     if (n0 + col >= Cout) continue;
     float t = 0.f;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
   }
 }
 
-__host__ __device__ constexpr int patch_it(int BM) { return ((BM / 16 + 2) * 18 * NCH + NT - 1) / NT; }
+__host__ __device__ constexpr int patch_it(int BM, int NTH) { return ((BM / 16 + 2) * 18 * NCH + NTH - 1) / NTH; }
 
 // ---------------------------------------------------------------------------------------------
 // Patch variant for unit-stride tap walks (forward stride-1 convs, every data-gradient /
@@ -380,16 +380,17 @@ __host__ __device__ constexpr int patch_it(int BM) { return ((BM / 16 + 2) * 18 
 // into registers at the first tap of the current chunk and written at its last.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_patch_kernel(const T* __restrict__ in, const T* __restrict__ wgt,
                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                           float* __restrict__ stats, ConvGeom g) {
-  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
+  constexpr int NTH = 64 * WGM * WGN, RPI = NTH / NCH;   // threads; patch pixels / weight rows per staging iteration
   constexpr int TLW = 16, TLH = BM / TLW;
   constexpr int EPC = Elem<T>::EPC, BK = NCH * EPC;
   constexpr int WTM = BM / WGM, WTN = BN / WGN, MI = WTM / 32, NI = WTN / 32;
-  constexpr int B_IT = (BN * NCH + NT - 1) / NT;
-  constexpr int P_IT = patch_it(BM);         // patch chunks per thread: (TLH+2)*(16+2) pixels * 8 chunks <= P_IT * 256
-  constexpr int MAXPIX = P_IT * NT / NCH;    // 192 (8x16 tile) / 352 (16x16 tile) patch pixels
+  constexpr int B_IT = (BN * NCH + NTH - 1) / NTH;
+  constexpr int P_IT = patch_it(BM, NTH);         // patch chunks per thread: (TLH+2)*(16+2) pixels * 8 chunks <= P_IT * 256
+  constexpr int MAXPIX = P_IT * NTH / NCH;    // 192 (8x16 tile) / 352 (16x16 tile) patch pixels
   constexpr int BS_BYTES = BN * ROWB;
   constexpr unsigned OOB = 0xFFFFFFF0u;
   using frag_t = typename Frag<T>::type;
@@ -432,8 +433,8 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
       const bool ok = inpatch && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
       poff[i] = ok ? (unsigned)((py * g.IW + px) * pix_bytes) + ch * 16u : OOB;
       plds[i] = inpatch ? pp * ROWB + ch * 16 : -1;
-      pp += NT / NCH;
-      px += NT / NCH;
+      pp += RPI;
+      px += RPI;
       while (px >= PW) { px -= PW; ++py; }
     }
   }
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
   unsigned boff[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int r = r0 + 32 * i, n = n0 + r;
+    const int r = r0 + RPI * i, n = n0 + r;
     boff[i] = (KT > 0 && r < BN && n < g.Cout) ? (unsigned)((size_t)n * Ktot_w * sizeof(T)) + ch * 16u : OOB;
   }
 
@@ -481,8 +482,8 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
     constexpr int set = decltype(SET)::value, buf = decltype(BUF)::value;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
-      if (B_IT * 32 <= BN || r0 + 32 * i < BN)
-        *reinterpret_cast<uint4*>(b_st + buf * BS_BYTES + i * 32 * ROWB) = breg[set][i];
+      if (B_IT * RPI <= BN || r0 + RPI * i < BN)
+        *reinterpret_cast<uint4*>(b_st + buf * BS_BYTES + i * RPI * ROWB) = breg[set][i];
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
     __syncthreads();
     constexpr int CPRO = BN * (int)sizeof(T) / 16;
     char* const obase = reinterpret_cast<char*>(out + g.out_coff + n0);
-    for (int i = tid; i < BM * CPRO; i += NT) {
+    for (int i = tid; i < BM * CPRO; i += NTH) {
       const int row = i / CPRO, c16 = i % CPRO;
       const long long opix = out_pixel(row);
       if (opix < 0) continue;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(NT, 2) void conv_patch_kernel(const T* __restrict__
 
 template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_patch(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
-  constexpr int TLW = 16, TLH = BM / TLW, MAXPIX = patch_it(BM) * NT / NCH;
+  constexpr int NTH = 64 * WGM * WGN, TLW = 16, TLH = BM / TLW, MAXPIX = patch_it(BM, NTH) * NTH / NCH;
   const long long nblk = (long long)g.B * ((g.MH + TLH - 1) / TLH) * ((g.MW + TLW - 1) / TLW) * ((g.Cout + BN - 1) / BN);
   if (nblk > 0x7fffffffLL) return fail(JSPSR_EINVAL, "conv: grid too large");
   const size_t lds_stage = (size_t)MAXPIX * ROWB + 2 * BN * ROWB, lds_out = (size_t)BM * (BN * sizeof(T) + 16);
@@ -655,7 +656,7 @@ int launch_patch(const void* in, const void* wgt, const float* bias, void* out, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NT), lds, s, static_cast<const T*>(in), static_cast<const T*>(wgt),
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTH), lds, s, static_cast<const T*>(in), static_cast<const T*>(wgt),
                      bias, static_cast<T*>(out), stats, g);
   return check_launch("conv_patch");
 }
@@ -696,12 +697,19 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
   constexpr int BKT = NCH * Elem<T>::EPC;
   if (!no_patch && g.iy_mul == 1 && g.ix_mul == 1 && g.nty >= 1 && g.ntx >= 1 && g.nty <= 3 && g.ntx <= 3 &&
       g.nty * g.ntx > 1 && g.Cin % BKT == 0 && (long long)(g.IW + 20) * 12 * g.in_cstride * (long long)sizeof(T) < 0xE0000000LL) {
-    if (g.Cout > 64) return launch_patch<T, 128, 128, 2, 2>(in, wgt, bias, out, stats, g, s);
+    static const int tall = [] { const char* e = getenv("JSPSR_CONV_TALL"); return e ? atoi(e) : 1; }();
+    const long long tiles16 = (long long)g.B * ((g.MH + 15) / 16) * ((g.MW + 15) / 16);
+    if (g.Cout > 64) {
+      // 16x16-pixel tile, 8 waves: the weight tile is staged once per 256 pixels instead of once per 128.  Measured
+      // on MI355X: +5 % on the 64x64x512-channel layers, -3..5 % on the full-resolution ones (one 8-wave workgroup
+      // per CU stalls as a whole at each stage barrier; two 4-wave workgroups cover each other) -> opt-in only
+      // (JSPSR_CONV_TALL=2).
+      if (tall >= 2 && tiles16 * ((g.Cout + 127) / 128) >= 512) return launch_patch<T, 256, 128, 4, 2>(in, wgt, bias, out, stats, g, s);
+      return launch_patch<T, 128, 128, 2, 2>(in, wgt, bias, out, stats, g, s);
+    }
     if (g.Cout > 32) {
       // 64 output channels: a 16x16-pixel tile (4 waves x 64 px x 64 ch) halves the weight-tile staging and the
       // fragment reads per MFMA of the 8x16 tile; worth it once the image has enough tiles to fill the chip
-      static const int tall = [] { const char* e = getenv("JSPSR_CONV_TALL"); return e ? atoi(e) : 1; }();
-      const long long tiles16 = (long long)g.B * ((g.MH + 15) / 16) * ((g.MW + 15) / 16);
       if (tall && tiles16 >= 1024) return launch_patch<T, 256, 64, 4, 1>(in, wgt, bias, out, stats, g, s);
       return launch_patch<T, 128, 64, 2, 2>(in, wgt, bias, out, stats, g, s);
     }

@@ -403,22 +403,38 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
           }
       }
     } else {
+      // 12 groups of (k-block, tap row): the fragments of group i+1 are requested before the three MFMAs of group i
+      // are issued (order pinned below; left alone the scheduler puts each read right before its use)
+      constexpr int NG = (U / 16) * 3;
+      bf16x8 a[2], bfr[2][3];
+      auto rd_tr = [](const char* p_) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p_));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p_ + 4 * P));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      auto rd = [&](int grp) {
+        const int kb = grp / 3, ky = grp % 3;
+        if (ky == 0) a[kb & 1] = rd_tr(gp + kb * 16 * P);
 #pragma unroll
-      for (int kb = 0; kb < U / 16; ++kb) {
-        const char* pa = gp + kb * 16 * P;
-        const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
-        const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 4 * P));
-        const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+        for (int kx = 0; kx < 3; ++kx) bfr[grp & 1][kx] = rd_tr(xp[ky] + (kb * 16 + kx) * P);
+      };
+      rd(0);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+      for (int grp = 0; grp < NG; ++grp) {
+        if (grp + 1 < NG) rd(grp + 1);
+        const int kb = grp / 3, ky = grp % 3;
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const char* pb = xp[ky] + (kb * 16 + kx) * P;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * P));
-            const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bv, acc[ky * 3 + kx], 0, 0, 0);
-          }
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb & 1], bfr[grp & 1][kx], acc[ky * 3 + kx], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
+        if (grp + 1 < NG) {
+          if ((grp + 1) % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       }
     }
   };

@@ -109,7 +109,7 @@ def test_conv_wgrad(dtype, B, H, W, Cin, Cout, k, stride, pad):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 256, 256, 64, 64), (5, 232, 250, 128, 40)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 256, 256, 64, 64), (5, 232, 250, 128, 40), (2, 256, 256, 64, 128), (3, 200, 216, 64, 200)])
 def test_conv_16x16_tile_path(dtype, B, H, W, Cin, Cout):
     """Layers with 33..64 output channels on rasters of >= 1024 16x16-pixel tiles take the tall-tile
     instantiation of the patch kernel (conv.hip: launch<T>): forward + BN partial statistics, ragged bottom/right
