@@ -79,7 +79,12 @@ class ResUnit(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
         self.stride, self.act, self.scale = stride, act, scale
 
+    fused = True   # one autograd node per block (ops._ResUnit); False = the op-by-op composition below
+
     def forward(self, x, dest=None):
+        if self.fused:
+            return E.res_unit(x, self.conv1, self.bn1, self.conv2, self.bn2, self.downsample, self.stride, self.scale,
+                              self.act, dest)
         y = E.conv_bn(x, self.conv1.weight, self.bn1, self.stride, 1, relu=True)
         if self.downsample is not None:
             r = E.conv_bn(x, self.downsample[0].weight, self.downsample[1], self.stride, 0)

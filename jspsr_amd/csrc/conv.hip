@@ -82,6 +82,29 @@ __device__ __forceinline__ void stats_epilogue(const f32x16 (&acc)[MI][NI], floa
   __syncthreads();
 }
 
+// 16 bytes of T plus 16 bytes of T, element-wise (fp32 add, one rounding): the epilogue's `+ addend`
+template <typename T>
+__device__ __forceinline__ uint4 add_packed(uint4 a, uint4 b) {
+  if constexpr (sizeof(T) == 4) {
+    float4 x = __builtin_bit_cast(float4, a), y = __builtin_bit_cast(float4, b);
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    return __builtin_bit_cast(uint4, x);
+  } else {
+    const unsigned* pa = &a.x;
+    const unsigned* pb = &b.x;
+    uint4 r;
+    unsigned* pr = &r.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = __uint_as_float(pa[i] << 16) + __uint_as_float(pb[i] << 16);
+      const float hi = __uint_as_float(pa[i] & 0xffff0000u) + __uint_as_float(pb[i] & 0xffff0000u);
+      const __bf16 l = (__bf16)lo, h = (__bf16)hi;
+      pr[i] = (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+    }
+    return r;
+  }
+}
+
 // UNI: Cin is a multiple of the stage depth BK, so every 16-byte chunk of a stage belongs to the
 // same tap -> the tap walk is wave-uniform (scalar registers, scalar offset of the buffer loads).
 // NBUF: LDS staging buffers.  2 = one barrier per stage; 1 = two barriers per stage but half the LDS,
@@ -322,8 +345,28 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
   char* Os = smem;
   const bool vec_ok = (g.Cout - n0 >= BN) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
                       (((g.out_coff + n0) * (int)sizeof(T)) % 16 == 0) &&
-                      ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+                      ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
+                      (!g.addend || (((reinterpret_cast<uintptr_t>(g.addend) & 15u) == 0) &&
+                                     ((g.add_cstride * (int)sizeof(T)) % 16 == 0) && ((n0 * (int)sizeof(T)) % 16 == 0)));
   if (vec_ok) {
+    constexpr int CPRO = BN * (int)sizeof(T) / 16;       // 16-byte chunks per output row
+    constexpr int O_IT = BM * CPRO / NT, A_PRE = O_IT <= 8 ? O_IT : 1;
+    static_assert(BM * CPRO % NT == 0, "epilogue rows");
+    // the addend's 16-byte pieces are requested up front: they fly during the accumulator -> LDS transpose and
+    // the barrier instead of one exposed memory latency per piece in the copy loop below
+    uint4 areg[A_PRE];
+    const bool add_pre = g.addend && O_IT <= 8;
+    if (add_pre) {
+#pragma unroll
+      for (int j = 0; j < A_PRE; ++j) {
+        const int i = tid + j * NT, row = i / CPRO, c16 = i % CPRO;
+        const long long opix = out_pixel(row);
+        areg[j] = make_uint4(0, 0, 0, 0);
+        if (opix >= 0)
+          areg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
+                                                    (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16);
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -337,14 +380,19 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
         }
       }
     __syncthreads();
-    constexpr int CPRO = BN * (int)sizeof(T) / 16;       // 16-byte chunks per output row
     char* const obase = reinterpret_cast<char*>(out + g.out_coff + n0);
-    for (int i = tid; i < BM * CPRO; i += NT) {
-      const int row = i / CPRO, c16 = i % CPRO;
+#pragma unroll
+    for (int j = 0; j < O_IT; ++j) {
+      const int i = tid + j * NT, row = i / CPRO, c16 = i % CPRO;
       const long long opix = out_pixel(row);
       if (opix < 0) continue;
-      const uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
+      uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
       if (CONV_ABLATE == 4 && v.x != 0x12345678u) continue;   // lab: no output stores
+      if (add_pre)
+        v = add_packed<T>(v, areg[j < A_PRE ? j : 0]);
+      else if (g.addend)
+        v = add_packed<T>(v, *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
+                                                              (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16));
       *reinterpret_cast<uint4*>(obase + opix * g.out_cstride * (long long)sizeof(T) + c16 * 16) = v;
     }
   } else {
@@ -361,6 +409,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
           if (ncol[ni] >= g.Cout) continue;
           float v = acc[mi][ni][e] + bv[ni];
           if (g.relu) v = fmaxf(v, 0.f);
+          if (g.addend) v = (float)(T)v + (float)static_cast<const T*>(g.addend)[opix * g.add_cstride + ncol[ni]];
           orow[ncol[ni]] = (T)v;
         }
       }
@@ -599,8 +648,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
   char* Os = smem;
   const bool vec_ok = (g.Cout - n0 >= BN) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
                       (((g.out_coff + n0) * (int)sizeof(T)) % 16 == 0) &&
-                      ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+                      ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
+                      (!g.addend || (((reinterpret_cast<uintptr_t>(g.addend) & 15u) == 0) &&
+                                     ((g.add_cstride * (int)sizeof(T)) % 16 == 0) && ((n0 * (int)sizeof(T)) % 16 == 0)));
   if (vec_ok) {
+    constexpr int CPRO = BN * (int)sizeof(T) / 16;       // 16-byte chunks per output row
+    constexpr int O_IT = BM * CPRO / NTH, A_PRE = O_IT <= 8 ? O_IT : 1;
+    static_assert(BM * CPRO % NTH == 0, "epilogue rows");
+    // the addend's 16-byte pieces are requested up front: they fly during the accumulator -> LDS transpose and
+    // the barrier instead of one exposed memory latency per piece in the copy loop below
+    uint4 areg[A_PRE];
+    const bool add_pre = g.addend && O_IT <= 8;
+    if (add_pre) {
+#pragma unroll
+      for (int j = 0; j < A_PRE; ++j) {
+        const int i = tid + j * NTH, row = i / CPRO, c16 = i % CPRO;
+        const long long opix = out_pixel(row);
+        areg[j] = make_uint4(0, 0, 0, 0);
+        if (opix >= 0)
+          areg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
+                                                    (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16);
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -614,13 +683,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
         }
       }
     __syncthreads();
-    constexpr int CPRO = BN * (int)sizeof(T) / 16;
     char* const obase = reinterpret_cast<char*>(out + g.out_coff + n0);
-    for (int i = tid; i < BM * CPRO; i += NTH) {
-      const int row = i / CPRO, c16 = i % CPRO;
+#pragma unroll
+    for (int j = 0; j < O_IT; ++j) {
+      const int i = tid + j * NTH, row = i / CPRO, c16 = i % CPRO;
       const long long opix = out_pixel(row);
       if (opix < 0) continue;
-      const uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
+      uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
+      if (add_pre)
+        v = add_packed<T>(v, areg[j < A_PRE ? j : 0]);
+      else if (g.addend)
+        v = add_packed<T>(v, *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
+                                                              (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16));
       *reinterpret_cast<uint4*>(obase + opix * g.out_cstride * (long long)sizeof(T) + c16 * 16) = v;
     }
   } else {
@@ -637,6 +711,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
           if (ncol[ni] >= g.Cout) continue;
           float v = acc[mi][ni][e] + bv[ni];
           if (g.relu) v = fmaxf(v, 0.f);
+          if (g.addend) v = (float)(T)v + (float)static_cast<const T*>(g.addend)[opix * g.add_cstride + ncol[ni]];
           orow[ncol[ni]] = (T)v;
         }
       }
@@ -807,8 +882,9 @@ extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack
 extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,
                                   int B, int OH, int OW, int Cg, int g_cstride, int g_coff, int IH, int IW,
                                   int Cin, int in_cstride, int in_coff, int KH, int KW, int stride, int pad,
-                                  int relu, jspsr_stream_t stream) {
+                                  int relu, const void* addend, int add_cstride, jspsr_stream_t stream) {
   if (int e = check_common(dtype, gout, wpack_t, gin, Cg, g_cstride, g_coff, in_cstride, in_coff, Cin, "conv2d_dgrad")) return e;
+  if (addend && add_cstride < Cin) return fail(JSPSR_EINVAL, "conv2d_dgrad: addend pitch %d < %d channels", add_cstride, Cin);
   if (B <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     return fail(JSPSR_EINVAL, "conv2d_dgrad: bad geometry");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -830,6 +906,7 @@ extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack
       g.iy_mul = 1; g.iy_add = (py + pad - g.ky0) / stride; g.ix_mul = 1; g.ix_add = (px + pad - g.kx0) / stride;
       g.sign = -1; g.KH = KH; g.KW = KW;
       g.oy_mul = stride; g.oy_add = py; g.ox_mul = stride; g.ox_add = px; g.relu = relu;
+      g.addend = addend; g.add_cstride = add_cstride;
       const int e = dtype == JSPSR_F32 ? launch<float>(gout, wpack_t, bias, gin, nullptr, g, s)
                                        : launch<__bf16>(gout, wpack_t, bias, gin, nullptr, g, s);
       if (e) return e;

@@ -43,7 +43,9 @@ struct ConvGeom {
   // written pixel of m-pixel (y', x'): (y'*oy_mul + oy_add, x'*ox_mul + ox_add)
   int oy_mul, oy_add, ox_mul, ox_add;
   int relu;               // epilogue ReLU
-  int accumulate;         // epilogue adds to what is already there (unused yet)
+  int accumulate;         // lab switch (JSPSR_CONV_NOXCD)
+  const void* addend;     // optional tensor on the written grid, added after bias/ReLU: out = [relu](acc + bias) + addend
+  int add_cstride;        // its channel pitch (channel 0 of the addend = channel out_coff of the written slice)
 };
 
 }  // namespace jspsr

@@ -88,6 +88,24 @@ def conv_bn(x, weight, bn: torch.nn.BatchNorm2d, stride=1, padding=0, relu=False
     return batch_norm(ops.conv2d(x, weight, None, stride, padding), bn, relu, residual, res_scale, dest=dest)
 
 
+def _bn_state(bn: torch.nn.BatchNorm2d):
+    training = bn.training or bn.running_mean is None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return (bn.running_mean, bn.running_var, bn.momentum, bn.eps, training)
+
+
+def res_unit(x, conv1, bn1, conv2, bn2, downsample, stride, scale, act, dest=None):
+    """BasicBlock (basics.py:88-123) as one autograd node (ops._ResUnit)."""
+    bns = [_bn_state(bn1), _bn_state(bn2)]
+    wd = gd = bd = None
+    if downsample is not None:
+        wd, gd, bd = downsample[0].weight, downsample[1].weight, downsample[1].bias
+        bns.append(_bn_state(downsample[1]))
+    return ops.res_unit(x, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias, wd, gd, bd,
+                        stride, scale, act, tuple(bns), dest)
+
+
 def channel_gate(x, w1, w2):
     """x * sigmoid(MLP(avgpool x) + MLP(maxpool x)), resnet_cbam.py:49-53 + basics.py:57-58."""
     if _gate_sync is not None:   # sharded inference: pooled statistics come from all strips

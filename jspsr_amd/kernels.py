@@ -103,9 +103,10 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
     return (out, st) if stats else out
 
 
-def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0):
+def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0, addend=None):
     """g (B,OH,OW,Cgs) NHWC, wpack_t [Cin][KH][KW][Cg] -> (B,IH,IW,Cin): data gradient of a conv /
-    forward of a transposed conv."""
+    forward of a transposed conv.  addend (B,IH,IW,Cin): added in the epilogue (a gradient arriving along
+    another path)."""
     _chk_s(g, "conv2d_dgrad")
     B, OH, OW, _ = g.shape
     Cgs = pitch(g)
@@ -113,11 +114,17 @@ def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None
     IH, IW = in_hw
     if out is None:
         out = torch.empty((B, IH, IW, Cin), dtype=g.dtype, device=g.device)
+    if addend is not None:
+        _chk_s(addend, "conv2d_dgrad addend")
+        if tuple(addend.shape) != (B, IH, IW, Cin) or addend.dtype != g.dtype:
+            raise ValueError(f"conv2d_dgrad: addend {tuple(addend.shape)} {addend.dtype} does not match the result")
     lib = _lib.load()
     _lib.check(lib.jspsr_conv2d_dgrad(_dt(g), g.data_ptr(), wpack_t.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                       B, OH, OW, Cg, Cgs, g_coff, IH, IW, Cin, pitch(out), out_coff,
-                                      KH, KW, stride, pad, int(relu), _stream()), "jspsr_conv2d_dgrad")
+                                      KH, KW, stride, pad, int(relu),
+                                      addend.data_ptr() if addend is not None else None,
+                                      pitch(addend) if addend is not None else 0, _stream()), "jspsr_conv2d_dgrad")
     return out
 
 

@@ -187,6 +187,37 @@ def test_conv_wgrad_3x3_channel_slices(dtype):
     assert _relerr(dW.cpu(), w.grad) < (3e-6 if dtype == torch.float32 else 1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", [
+    (2, 24, 40, 64, 64, 3, 1, 1),     # patch kernel, 64-wide written tensor
+    (1, 40, 36, 128, 64, 3, 1, 1),    # patch kernel, 128-wide written tensor
+    (1, 32, 32, 192, 128, 3, 2, 1),   # stride 2: four phase launches, each written pixel gets the addend once
+    (2, 16, 16, 64, 128, 1, 2, 0),    # 1x1 stride 2: three of the four phases have no tap at all
+    (1, 17, 19, 200, 8, 3, 1, 1),     # ragged written channels -> scalar epilogue
+    (4, 256, 256, 64, 64, 3, 1, 1),   # 16x16-pixel tile instantiation
+])
+def test_conv_dgrad_addend(dtype, B, H, W, Cin, Cout, k, stride, pad):
+    """gin = dgrad(gout) + addend in one launch: the meeting point of a BasicBlock's two gradient paths
+    (basics.py:113-122).  Checked against the two-step formulation with the same roundings."""
+    K = _k()
+    e = K.epc(dtype)
+    if Cin % e:
+        pytest.skip("channel granularity")
+    Cg = (Cout + e - 1) // e * e
+    g = torch.Generator().manual_seed(B * 13 + H + Cin + Cout)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    go = F.pad(torch.randn(B, Cout, OH, OW, generator=g), (0, 0, 0, 0, 0, Cg - Cout))
+    wide = torch.randn(B, H, W, Cin + 2 * e, generator=g).cuda().to(dtype)
+    addend = wide.narrow(3, e, Cin)                  # a channel slice: pitch != channels
+    wpt = K.pack_weight(w.cuda(), 1, Cg, dtype)
+    god = _nhwc(go).to(dtype)
+    plain = K.conv2d_dgrad(god, wpt, (H, W), stride, pad)
+    fused = K.conv2d_dgrad(god, wpt, (H, W), stride, pad, addend=addend)
+    ref = (plain.float() + addend.float()).to(dtype)  # same two roundings as the kernel's epilogue
+    assert torch.equal(fused, ref)
+
+
 def test_conv_transpose_wgrad():
     """ConvTranspose2d weight (I,O,kh,kw): G = its input, X = grad of its output."""
     K = _k()
