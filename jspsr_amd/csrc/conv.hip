@@ -343,7 +343,9 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
   // the launcher sizes dynamic LDS as max(staging, BM * OPITCH)
   if (NBUF == 1) __syncthreads();
   char* Os = smem;
-  const bool vec_ok = (g.Cout - n0 >= BN) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
+  // whole 16-byte pieces of channels: a last N tile that is only partly inside Cout still takes the vector path
+  // (pieces at or beyond Cout are skipped in the copy loop)
+  const bool vec_ok = (g.Cout % EPC == 0) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
                       (((g.out_coff + n0) * (int)sizeof(T)) % 16 == 0) &&
                       ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
                       (!g.addend || (((reinterpret_cast<uintptr_t>(g.addend) & 15u) == 0) &&
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
         const int i = tid + j * NT, row = i / CPRO, c16 = i % CPRO;
         const long long opix = out_pixel(row);
         areg[j] = make_uint4(0, 0, 0, 0);
-        if (opix >= 0)
+        if (opix >= 0 && n0 + c16 * EPC < g.Cout)
           areg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
                                                     (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16);
       }
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
     for (int j = 0; j < O_IT; ++j) {
       const int i = tid + j * NT, row = i / CPRO, c16 = i % CPRO;
       const long long opix = out_pixel(row);
-      if (opix < 0) continue;
+      if (opix < 0 || n0 + c16 * EPC >= g.Cout) continue;
       uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
       if (CONV_ABLATE == 4 && v.x != 0x12345678u) continue;   // lab: no output stores
       if (add_pre)
@@ -646,7 +648,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
   }
   constexpr int OPITCH = BN * (int)sizeof(T) + 16;
   char* Os = smem;
-  const bool vec_ok = (g.Cout - n0 >= BN) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
+  // whole 16-byte pieces of channels: a last N tile that is only partly inside Cout still takes the vector path
+  // (pieces at or beyond Cout are skipped in the copy loop)
+  const bool vec_ok = (g.Cout % EPC == 0) && ((g.out_cstride * (int)sizeof(T)) % 16 == 0) &&
                       (((g.out_coff + n0) * (int)sizeof(T)) % 16 == 0) &&
                       ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) &&
                       (!g.addend || (((reinterpret_cast<uintptr_t>(g.addend) & 15u) == 0) &&
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
         const int i = tid + j * NTH, row = i / CPRO, c16 = i % CPRO;
         const long long opix = out_pixel(row);
         areg[j] = make_uint4(0, 0, 0, 0);
-        if (opix >= 0)
+        if (opix >= 0 && n0 + c16 * EPC < g.Cout)
           areg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
                                                     (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16);
       }
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
     for (int j = 0; j < O_IT; ++j) {
       const int i = tid + j * NTH, row = i / CPRO, c16 = i % CPRO;
       const long long opix = out_pixel(row);
-      if (opix < 0) continue;
+      if (opix < 0 || n0 + c16 * EPC >= g.Cout) continue;
       uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
       if (add_pre)
         v = add_packed<T>(v, areg[j < A_PRE ? j : 0]);
