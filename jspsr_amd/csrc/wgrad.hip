@@ -487,7 +487,7 @@ struct PatchPlan {
   int rows_per_blk, row_blks, units;
 };
 
-// Units (strip x row range) per (G tile, X chunk) pair: enough workgroups to fill the chip twice over, but rows
+// Units (strip x row range) per (G tile, X chunk) pair: one full wave of workgroups over the chip, but rows
 // per workgroup >= 8 so the two halo rows stay a small part of the staging.
 template <typename T>
 PatchPlan make_patch_plan(int B, int H, int W, int Cg, int Cx) {
@@ -496,7 +496,8 @@ PatchPlan make_patch_plan(int B, int H, int W, int Cg, int Cx) {
   if (W % U || Cg < 32 || Cx < 32) return p;
   const long long pairs = (long long)((Cg + 63) / 64) * ((Cx + 63) / 64);
   const long long strips = (long long)B * (W / U);
-  long long want = (640 + pairs * strips - 1) / (pairs * strips);   // row blocks per strip
+  static const int target = [] { const char* e = getenv("JSPSR_WGRAD_UNITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();   // 2 resident workgroups x 256 CUs (swept 256..1024 on MI355X)
+  long long want = (target + pairs * strips - 1) / (pairs * strips);   // row blocks per strip
   if (want < 1) want = 1;
   int rows = (int)((H + want - 1) / want);
   if (rows < 8) rows = H < 8 ? H : 8;

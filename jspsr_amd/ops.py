@@ -110,6 +110,22 @@ def pad_channels(x: torch.Tensor, mult: int) -> torch.Tensor:
     return x if p == 0 else torch.nn.functional.pad(x, (0, p))
 
 
+def _wgrad_into(param, G, X, R, C, KH, KW, stride, pad):
+    """Weight gradient of one conv.  If the parameter's .grad lives in a GradReducer's flat buffer (opted in through
+    `_jspsr_direct_grad`), the ordered slab reduction adds straight into it and the autograd node reports no
+    gradient for that input -- the per-parameter `grad += dW` pass disappears; the reducer's bucket bookkeeping is
+    notified by hand.  Otherwise returns dW for autograd to accumulate."""
+    gbuf = param.grad if param is not None and getattr(param, "_jspsr_direct_grad", False) else None
+    if (gbuf is not None and gbuf.dtype == torch.float32 and gbuf.is_contiguous() and gbuf.is_cuda
+            and tuple(gbuf.shape) == (R, C, KH, KW)):
+        K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=gbuf, accumulate=True)
+        ready = getattr(param, "_jspsr_grad_ready", None)
+        if ready is not None:
+            ready(param)
+        return None
+    return K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad)
+
+
 class SliceBuffer:
     """A wide NHWC buffer that several operators fill channel slice by channel slice -- the reference's
     ``torch.cat((a, b, c), 1)`` (Guide, basics.py:134; skip concats JSPSR.py:355-368; spn.py:63) without the copy.
@@ -167,6 +183,7 @@ class _Conv(torch.autograd.Function):
         if Cp % e:
             raise ValueError(f"conv: input channels {Cp} must be padded to a multiple of {e} (ops.pad_channels)")
         w = weight.detach().contiguous()
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
         bias_d = bias.detach().contiguous() if bias is not None else None
         if not transposed:
             O, I, KH, KW = w.shape
@@ -220,14 +237,14 @@ class _Conv(torch.autograd.Function):
                     raise RuntimeError("conv backward: gradient w.r.t. a channel-padded input is not supported")
                 dx = K.conv2d_dgrad(dz, K.pack_weight(w, 1, Cg, cdt), (H, W), stride, pad)
             if ctx.needs_input_grad[1]:
-                dW = K.conv2d_wgrad(dz, x, O, I, KH, KW, stride, pad)
+                dW = _wgrad_into(ctx.wparam, dz, x, O, I, KH, KW, stride, pad)
         else:
             I, O, KH, KW = w.shape
             if ctx.needs_input_grad[0]:
                 # d/dx of a transposed conv = ordinary stride-2 conv of the fine-grid gradient
                 dx = K.conv2d_forward(dz, K.pack_weight(w, 0, Cg, cdt), None, 2, 1, False)
             if ctx.needs_input_grad[1]:
-                dW = K.conv2d_wgrad(x, dz, I, O, KH, KW, 2, 1)
+                dW = _wgrad_into(ctx.wparam, x, dz, I, O, KH, KW, 2, 1)
         return dx, dW, dbias, None, None, None, None, None, None
 
 
@@ -325,6 +342,7 @@ class _ResUnit(torch.autograd.Function):
         out_v = dest[0].slice(dest[1], O, z1.shape[:3]) if dest is not None else None
         z2, out, m2, i2 = conv_bn(y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale), out_v)
         ctx.cfg = (stride, float(scale), bool(act), has_d, tr1, tr2, trd)
+        ctx.wparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (w1, w2, wd))
         ctx.save_for_backward(x, w1d, g1d, b1d, z1, m1, i1, y1, w2d, g2d, b2d, z2, m2, i2, out if act else None,
                               wdd, gdd, bdd, zd, md, idd)
         return out
@@ -343,17 +361,18 @@ class _ResUnit(torch.autograd.Function):
                                             want_dres=(need_x or has_d), beta=b2)
         if dres is None:
             dres = dout
-        dW2 = K.conv2d_wgrad(dz2, y1, O, O, 3, 3, 1, 1)
+        p1, p2, pd = ctx.wparams
+        dW2 = _wgrad_into(p2, dz2, y1, O, O, 3, 3, 1, 1)
         dy1 = K.conv2d_dgrad(dz2, K.pack_weight(w2, 1, O, cdt), y1.shape[1:3], 1, 1)
         del dz2
         dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1)
         del dy1
-        dW1 = K.conv2d_wgrad(dz1, x, O, Cin, 3, 3, stride, 1)
+        dW1 = _wgrad_into(p1, dz1, x, O, Cin, 3, 3, stride, 1)
         dWd = dgd = dbd = None
         side = dres                      # what reaches x along the shortcut
         if has_d:
             dzd, _, dgd, dbd = K.bn_backward(dres, None, zd, gd, md, idd, trd, 0, 1.0, beta=bd)
-            dWd = K.conv2d_wgrad(dzd, x, O, Cin, 1, 1, stride, 0)
+            dWd = _wgrad_into(pd, dzd, x, O, Cin, 1, 1, stride, 0)
             side = K.conv2d_dgrad(dzd, K.pack_weight(wd, 1, O, cdt), (H, W), stride, 0) if need_x else None
         dx = None
         if need_x:

@@ -99,3 +99,29 @@ def test_b2_dummy_batch_like_torchinfo():
         y = m(torch.rand(2, 1, 128, 128, device="cuda"), torch.rand(2, 3, 128, 128, device="cuda"),
               torch.rand(2, 15, 128, 128, device="cuda"))
     assert y.shape == (2, 1, 128, 128) and torch.isfinite(y).all()
+
+
+def test_weight_gradients_straight_into_the_flat_buffer():
+    """With a GradReducer the conv weight-gradient kernels add directly into the reducer's flat buffer and the
+    autograd node reports no gradient for the weight (ops._wgrad_into).  Same numbers as autograd's own
+    accumulation, two steps in a row (the buffer is re-zeroed in between), every parameter."""
+    from jspsr_amd.JSPSR import Model
+    from jspsr_amd.ddp import GradReducer
+    torch.manual_seed(0)
+    ic = dict(MSK, COP30=1)
+    a, b = Model(ic, num_feature=8).cuda(), Model(ic, num_feature=8).cuda()
+    b.load_state_dict(a.state_dict())
+    inputs, gt = R.synthetic_batch(2, 32, 64, True, seed=5, dtype=torch.float32)
+    inputs = [t.cuda() for t in inputs]
+    probe = R.probe_gradient((2, 1, 32, 64), 7, torch.float32).cuda()
+    red = GradReducer(b.parameters())
+    direct = [p for p in b.parameters() if getattr(p, "_jspsr_direct_grad", False)]
+    assert len(direct) > 50
+    for _ in range(2):
+        a.zero_grad(set_to_none=True)
+        (a(*inputs) * probe).mean().backward()
+        red.zero_grad()
+        (b(*inputs) * probe).mean().backward()
+        red.finish()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert pb.grad.data_ptr() >= red.flat.data_ptr() and torch.equal(pa.grad, pb.grad), n
