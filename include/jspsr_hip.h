@@ -151,11 +151,12 @@ int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, const void*
 /* Backward of the above.  dy is the gradient w.r.t. y.  relu: 0 = none; 1 = mask from the saved output
  * (y > 0); 2 = mask recomputed from x as gamma*xhat + beta > 0 (valid without a residual; y is not read).
  * dx (dense, pitch C) = grad w.r.t. x; dres (dense, may be NULL) = grad w.r.t. res;
- * dgamma, dbeta [C] overwritten. */
+ * dgamma, dbeta [C]: overwritten, or added to when accumulate != 0 (gradients landing directly in a
+ * caller-owned accumulation buffer). */
 int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
                       const void* x, int x_cs, int x_coff, const float* gamma, const float* beta, const float* save_mean,
                       const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
-                      float* dgamma, float* dbeta, long long npix, int C, void* workspace,
+                      float* dgamma, float* dbeta, int accumulate, long long npix, int C, void* workspace,
                       jspsr_stream_t stream);
 
 /* Backward of the conv epilogue `y = [relu](conv + bias)` of the BN-free Basic2d (basics.py:36-53):

@@ -125,7 +125,7 @@ class Model(nn.Module):
         dem, img, msk, canopy, coord = self.parse_input(
             self.flag_dem_img, self.flag_dem_msk, self.flag_dem_canopy, self.flag_dem_coord, *in_tensor)
         aux = msk if msk is not None else (canopy if canopy is not None else coord)
-        with E.compute_dtype(self.compute_dtype):
+        with E.compute_dtype(self.compute_dtype), E.count_batches():
             return self._forward(dem, img, aux)
 
     def _forward(self, dem, img, aux):

@@ -134,7 +134,7 @@ class Model(nn.Module):
         depth, img, _, _, _ = _JSPSR.parse_input(True, False, False, False, *in_tensor)
         if depth.shape[2] % 16 or depth.shape[3] % 16:
             raise ValueError("LRRU needs H and W to be multiples of 16 (five stride-2 stages)")
-        with E.compute_dtype(self.compute_dtype):
+        with E.compute_dtype(self.compute_dtype), E.count_batches():
             return self._forward(depth, img)
 
     def _step(self, current, context, enc):

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("JSPSR_LAB_LIB") or os.path.join(_HERE, "lib", "libjspsr_hip.so")  # JSPSR_LAB_LIB: kernel-lab builds only
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lock = threading.Lock()
 _lib = None
@@ -39,7 +39,7 @@ SIGNATURES = {
     "jspsr_bn_forward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
                                c_i, c_f, c_p, c_p, c_ll, c_i, c_p, c_i, c_p, c_p]),
     "jspsr_bn_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_f,
-                                c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_p]),
+                                c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p]),
     "jspsr_act_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_ll, c_i, c_p, c_p]),
     "jspsr_gate_pool": (c_i, [c_i, c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_p]),
     "jspsr_gate_scale": (c_i, [c_i, c_p, c_p, c_p, c_i, c_ll, c_i, c_p]),

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(TX * TY) void bn_bwd_reduce_kernel(const T* __restr
 // dbeta = sum dz ; dgamma = sum dz*xhat ; coefficients for the apply pass
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, long long count,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       int training, float res_scale, float* __restrict__ dgamma,
+                                       int training, float res_scale, int accumulate, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef) {
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel
   if (c >= C) return;
@@ -320,8 +320,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
   const double sx = wave_sum_rows(partial, rows, (size_t)2 * C, (size_t)C + c);
   if ((threadIdx.x & 63) != 0) return;
   // the BN branch sees dz * res_scale
-  dbeta[c] = (float)(s * res_scale);
-  dgamma[c] = (float)(sx * res_scale);
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)(s * res_scale);
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)(sx * res_scale);
   const float k = gamma[c] * invstd[c] * res_scale;
   coef[c] = k;                                                     // dx = k * (dz - a - xhat * b)
   coef[C + c] = training ? (float)(s / (double)count) : 0.f;        // a = mean(dz)
@@ -600,7 +600,7 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
 extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
                                  const void* x, int x_cs, int x_coff, const float* gamma, const float* beta, const float* save_mean,
                                  const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
-                                 float* dgamma, float* dbeta, long long npix, int C, void* workspace,
+                                 float* dgamma, float* dbeta, int accumulate, long long npix, int C, void* workspace,
                                  jspsr_stream_t stream) {
   if (int e = check_c(dtype, C, "bn_backward")) return e;
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || npix <= 0 ||
@@ -619,7 +619,7 @@ extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_co
                                      static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, relu, g, partial));
   if (int e = check_launch("bn_bwd_reduce")) return e;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, C, npix, gamma,
-                     save_invstd, training, res_scale, dgamma, dbeta, coef);
+                     save_invstd, training, res_scale, accumulate, dgamma, dbeta, coef);
   if (int e = check_launch("bn_bwd_finalize")) return e;
   DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
                                      static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,

@@ -47,12 +47,13 @@ class GradReducer:
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
-        # conv weights: the weight-gradient kernels add straight into the flat buffer (ops._wgrad_into) and
-        # report readiness here instead of through autograd's accumulation hook
+        # conv weights and BatchNorm scale/shift: the gradient kernels add straight into the flat buffer
+        # (ops._wgrad_into, ops._bn_sink) and report readiness here instead of through autograd's accumulation
+        # hook; operators that do not know the protocol (biases, propagation parameters) keep returning their
+        # gradients to autograd
         for p in self.params:
-            if p.dim() == 4:
-                p._jspsr_direct_grad = True
-                p._jspsr_grad_ready = self._hook if self.world > 1 else None
+            p._jspsr_direct_grad = True
+            p._jspsr_grad_ready = self._hook if self.world > 1 else None
 
     def zero_grad(self):
         """Gradients alias the flat buffer: zero it in one kernel, keep the aliases."""

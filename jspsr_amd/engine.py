@@ -69,12 +69,47 @@ def conv_transpose2d(x, weight):
     return ops.conv_transpose2d(x, weight)
 
 
+_nbt_pending = None   # inside `count_batches()`: the BatchNorm step counters to bump, once, at the end
+
+
+class count_batches:
+    """BatchNorm2d bumps `num_batches_tracked` once per training forward (one tiny kernel per layer, 70 per
+    step for JSPSR).  Inside this context the counters are collected and bumped by one multi-tensor add."""
+
+    def __enter__(self):
+        global _nbt_pending
+        self.prev, _nbt_pending = _nbt_pending, []
+        return self
+
+    def __exit__(self, *a):
+        global _nbt_pending
+        todo, _nbt_pending = _nbt_pending, self.prev
+        if todo and a[0] is None:
+            seen = {}
+            for t in todo:                       # a layer applied k times in one forward counts k batches
+                seen[id(t)] = (t, seen.get(id(t), (t, 0))[1] + 1)
+            once = [t for t, k in seen.values() if k == 1]
+            if once:
+                torch._foreach_add_(once, 1)
+            for t, k in seen.values():
+                if k > 1:
+                    t += k
+        return False
+
+
+def _count_batch(bn):
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _nbt_pending is not None:
+            _nbt_pending.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
+
+
 def batch_norm(x, bn: torch.nn.BatchNorm2d, relu=False, residual=None, res_scale=1.0, partial=None, dest=None):
     """BatchNorm2d (+ `* res_scale + residual`) (+ ReLU): basics.py:113-123.  dest = (SliceBuffer, channel):
     write the result into that channel slice instead of a fresh tensor."""
     training = bn.training or bn.running_mean is None
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    _count_batch(bn)
     return ops.batch_norm(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, training,
                           relu, residual, res_scale, partial, dest)
 
@@ -90,8 +125,7 @@ def conv_bn(x, weight, bn: torch.nn.BatchNorm2d, stride=1, padding=0, relu=False
 
 def _bn_state(bn: torch.nn.BatchNorm2d):
     training = bn.training or bn.running_mean is None
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    _count_batch(bn)
     return (bn.running_mean, bn.running_var, bn.momentum, bn.eps, training)
 
 

@@ -194,14 +194,23 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
     return out, mean, invstd
 
 
-def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False, beta=None):
-    """-> (dx, dres or None, dgamma, dbeta).  relu: False/0, True/1 (mask from y) or 2 (mask from x, needs beta)."""
+def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False, beta=None,
+                grads_into=None):
+    """-> (dx, dres or None, dgamma, dbeta).  relu: False/0, True/1 (mask from y) or 2 (mask from x, needs beta).
+    grads_into = (dgamma_buf, dbeta_buf): add the parameter gradients to those fp32 buffers instead of
+    returning fresh tensors (then dgamma, dbeta come back as None)."""
     _chk_s(dy, "bn_backward")
     B, H, W, C = x.shape
     dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
     dres = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device) if want_dres else None
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    if grads_into is not None:
+        dgamma, dbeta = grads_into
+        for t in (dgamma, dbeta):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C or not t.is_cuda:
+                raise ValueError("bn_backward: grads_into buffers must be contiguous fp32 of C elements on the GPU")
+    else:
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     dt = _dt(x)
     ws = _workspace(dt, C, 1, x.device)
     lib = _lib.load()
@@ -210,7 +219,10 @@ def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, wa
                                      beta.data_ptr() if beta is not None else None,
                                      mean.data_ptr(), invstd.data_ptr(), int(training), int(relu), float(res_scale),
                                      dx.data_ptr(), dres.data_ptr() if dres is not None else None, dgamma.data_ptr(),
-                                     dbeta.data_ptr(), B * H * W, C, ws.data_ptr(), _stream()), "jspsr_bn_backward")
+                                     dbeta.data_ptr(), int(grads_into is not None), B * H * W, C, ws.data_ptr(),
+                                     _stream()), "jspsr_bn_backward")
+    if grads_into is not None:
+        return dx, dres, None, None
     return dx, dres, dgamma, dbeta
 
 

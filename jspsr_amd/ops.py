@@ -126,6 +126,25 @@ def _wgrad_into(param, G, X, R, C, KH, KW, stride, pad):
     return K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad)
 
 
+def _bn_sink(gparam, bparam):
+    """(dgamma_buf, dbeta_buf) if both BatchNorm parameters' .grad live in a GradReducer's flat buffer, else None;
+    see _wgrad_into."""
+    bufs = []
+    for p_ in (gparam, bparam):
+        g_ = p_.grad if p_ is not None and getattr(p_, "_jspsr_direct_grad", False) else None
+        if g_ is None or g_.dtype != torch.float32 or not g_.is_contiguous() or not g_.is_cuda or g_.dim() != 1:
+            return None
+        bufs.append(g_)
+    return tuple(bufs)
+
+
+def _bn_ready(gparam, bparam):
+    for p_ in (gparam, bparam):
+        ready = getattr(p_, "_jspsr_grad_ready", None)
+        if ready is not None:
+            ready(p_)
+
+
 class SliceBuffer:
     """A wide NHWC buffer that several operators fill channel slice by channel slice -- the reference's
     ``torch.cat((a, b, c), 1)`` (Guide, basics.py:134; skip concats JSPSR.py:355-368; spn.py:63) without the copy.
@@ -277,6 +296,7 @@ class _BatchNorm(torch.autograd.Function):
         # without a residual the ReLU mask is a function of x alone: the backward recomputes it (mode 2)
         # instead of reading the saved output
         mode = 0 if not relu else (1 if res is not None else 2)
+        ctx.gb = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (gamma, beta))
         ctx.cfg = (training, mode, rs, res is not None)
         ctx.save_for_backward(x, y if mode == 1 else None, gamma.detach(), beta.detach(), mean, invstd)
         return y
@@ -285,8 +305,11 @@ class _BatchNorm(torch.autograd.Function):
     def backward(ctx, dy):
         training, relu, rs, has_res = ctx.cfg
         x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        sink = _bn_sink(*ctx.gb)
         dx, dres, dgamma, dbeta = K.bn_backward(K.nhwc(dy), y, x, gamma, mean, invstd, training, relu, rs,
-                                                want_dres=has_res and ctx.needs_input_grad[9], beta=beta)
+                                                want_dres=has_res and ctx.needs_input_grad[9], beta=beta, grads_into=sink)
+        if sink is not None:
+            _bn_ready(*ctx.gb)
         if has_res and ctx.needs_input_grad[9] and dres is None:
             dres = dy
         return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
@@ -343,6 +366,7 @@ class _ResUnit(torch.autograd.Function):
         z2, out, m2, i2 = conv_bn(y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale), out_v)
         ctx.cfg = (stride, float(scale), bool(act), has_d, tr1, tr2, trd)
         ctx.wparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (w1, w2, wd))
+        ctx.bparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (g1, b1, g2, b2, gd, bd))
         ctx.save_for_backward(x, w1d, g1d, b1d, z1, m1, i1, y1, w2d, g2d, b2d, z2, m2, i2, out if act else None,
                               wdd, gdd, bdd, zd, md, idd)
         return out
@@ -357,21 +381,30 @@ class _ResUnit(torch.autograd.Function):
         dout = K.nhwc(dout)
         need_x = ctx.needs_input_grad[0]
         # bn2 (+ residual split): dz2 for the conv branch, dres for the shortcut
+        pg1, pb1, pg2, pb2, pgd, pbd = ctx.bparams
+        sink2, sink1 = _bn_sink(pg2, pb2), _bn_sink(pg1, pb1)
         dz2, dres, dg2, db2 = K.bn_backward(dout, out, z2, g2, m2, i2, tr2, 1 if act else 0, scale,
-                                            want_dres=(need_x or has_d), beta=b2)
+                                            want_dres=(need_x or has_d), beta=b2, grads_into=sink2)
+        if sink2 is not None:
+            _bn_ready(pg2, pb2)
         if dres is None:
             dres = dout
         p1, p2, pd = ctx.wparams
         dW2 = _wgrad_into(p2, dz2, y1, O, O, 3, 3, 1, 1)
         dy1 = K.conv2d_dgrad(dz2, K.pack_weight(w2, 1, O, cdt), y1.shape[1:3], 1, 1)
         del dz2
-        dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1)
+        dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1, grads_into=sink1)
+        if sink1 is not None:
+            _bn_ready(pg1, pb1)
         del dy1
         dW1 = _wgrad_into(p1, dz1, x, O, Cin, 3, 3, stride, 1)
         dWd = dgd = dbd = None
         side = dres                      # what reaches x along the shortcut
         if has_d:
-            dzd, _, dgd, dbd = K.bn_backward(dres, None, zd, gd, md, idd, trd, 0, 1.0, beta=bd)
+            sinkd = _bn_sink(pgd, pbd)
+            dzd, _, dgd, dbd = K.bn_backward(dres, None, zd, gd, md, idd, trd, 0, 1.0, beta=bd, grads_into=sinkd)
+            if sinkd is not None:
+                _bn_ready(pgd, pbd)
             dWd = _wgrad_into(pd, dzd, x, O, Cin, 1, 1, stride, 0)
             side = K.conv2d_dgrad(dzd, K.pack_weight(wd, 1, O, cdt), (H, W), stride, 0) if need_x else None
         dx = None
