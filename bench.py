@@ -82,12 +82,16 @@ def time_k1(model, inputs, iters=20):
     def fwd(i):
         ops.prop_forward_raw(dem, sets[i % nset][0], sets[i % nset][1], w, b, 1.0, out)
 
-    def bwd(i):
+    def bwd(i):   # the streaming kernel alone: what rocprof lists as prop_bwd_kernel
+        ops.prop_backward_raw(gout, dem, sets[i % nset][0], sets[i % nset][1], w, gsets[i % nset][0],
+                              gsets[i % nset][1], None, None, ws)
+
+    def bwd_call(i):   # the whole C-ABI call: streaming kernel + 10-workgroup fold of the parameter gradients
         ops.prop_backward_raw(gout, dem, sets[i % nset][0], sets[i % nset][1], w, gsets[i % nset][0],
                               gsets[i % nset][1], gw, gb, ws)
 
     res = {}
-    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+    for name, fn in (("fwd", fwd), ("bwd", bwd), ("bwd_call", bwd_call)):
         for i in range(3):
             fn(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -107,15 +111,17 @@ def time_k1(model, inputs, iters=20):
     if os.path.exists(pmc):
         traffic = json.load(open(pmc))
     return {
-        "bound": "hbm", "kernel": "prop_bwd_kernel<16> (+ 10-block finalize)", "achieved": round(bw_b, 1),
+        "bound": "hbm", "kernel": "prop_bwd_kernel<16>", "achieved": round(bw_b, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bw_b / HBM_PEAK_GBS, 4),
         "traffic": traffic.get("bwd_bytes_per_launch") if traffic else None,
         "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2),
+        "us_per_call_with_fold": round(res["bwd_call"] * 1e6, 2),
         "forward": {"kernel": "prop_fwd_kernel<16>", "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get("fwd_bytes_per_launch") if traffic else None,
                     "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2)},
         "note": "algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / "
-                "mean launch duration (events on the launch stream, back-to-back launches); traffic = PMC "
+                "mean launch duration (events on the launch stream, back-to-back launches of that kernel alone; "
+                "us_per_call_with_fold adds the 10-workgroup fold launch of the backward C-ABI call); traffic = PMC "
                 "FETCH_SIZE+WRITE_SIZE per launch from profiles/k1_pmc.json (separate rocprofv3 --pmc passes)",
     }
 

@@ -60,12 +60,18 @@ size_t jspsr_prop_backward_workspace_bytes(int B, int H, int W);
  * grad_wk [9], grad_b0 [1] are overwritten (not accumulated).  grad wrt dem is not produced:
  * every caller detaches it (models/JSPSR.py:372, models/LRRU.py:453,467,481,496).
  * workspace: jspsr_prop_backward_workspace_bytes() bytes, 16-byte aligned.
+ * Two launches: the streaming kernel (writes grad_weight / grad_offset and one row of 10 partial sums per
+ * workgroup into the workspace) and a 10-workgroup fold of those rows into grad_wk / grad_b0.  With
+ * grad_wk == grad_b0 == NULL only the first is launched; jspsr_prop_backward_fold_f32 is the second on its own.
  */
 int jspsr_prop_backward_f32(const float* grad_out, const float* dem, const float* weight,
                             const float* offset, int offset_channels, const float* wk,
                             float* grad_weight, float* grad_offset, float* grad_wk,
                             float* grad_b0, void* workspace, int B, int H, int W,
                             jspsr_stream_t stream);
+
+int jspsr_prop_backward_fold_f32(const void* workspace, int B, int H, int W, float* grad_wk, float* grad_b0,
+                                 jspsr_stream_t stream);
 
 /* ---- K2: convolutions on the matrix cores (implicit GEMM, NHWC) ---------------------------
  * Replace the reference's nn.Conv2d / nn.ConvTranspose2d calls and their autograd

@@ -433,7 +433,7 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
                                        float* grad_weight, float* grad_offset, float* grad_wk,
                                        float* grad_b0, void* workspace, int B, int H, int W,
                                        jspsr_stream_t stream) {
-  if (!grad_out || !dem || !weight || !offset || !wk || !grad_weight || !grad_offset || !grad_wk || !grad_b0 || !workspace)
+  if (!grad_out || !dem || !weight || !offset || !wk || !grad_weight || !grad_offset || !workspace || (!grad_wk != !grad_b0))
     return jspsr::fail(JSPSR_EINVAL, "prop_backward: null pointer");
   if (offset_channels != 16 && offset_channels != 18)
     return jspsr::fail(JSPSR_EINVAL, "prop_backward: offset_channels must be 16 or 18, got %d", offset_channels);
@@ -457,6 +457,17 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
 #undef BY_VEC
 #undef BY_PX
   if (int e = jspsr::check_launch("prop_backward")) return e;
+  if (!grad_wk) return JSPSR_OK;   // partial rows only: the caller folds them later (jspsr_prop_backward_fold_f32)
   hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, g.nblk, grad_wk, grad_b0);
   return jspsr::check_launch("prop_backward_finalize");
+}
+
+extern "C" int jspsr_prop_backward_fold_f32(const void* workspace, int B, int H, int W, float* grad_wk, float* grad_b0,
+                                            jspsr_stream_t stream) {
+  if (!workspace || !grad_wk || !grad_b0) return jspsr::fail(JSPSR_EINVAL, "prop_backward_fold: null pointer");
+  Geom g;
+  if (int e = make_geom(B, H, W, g)) return e;
+  hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(workspace), g.nblk, grad_wk, grad_b0);
+  return jspsr::check_launch("prop_backward_fold");
 }

@@ -32,12 +32,19 @@ def prop_forward_raw(dem, weight, offset, w, b, scale, out):
 
 
 def prop_backward_raw(grad_out, dem, weight, offset, w, gweight, goffset, gw, gb, ws):
+    """gw = gb = None: the streaming kernel alone (partial rows stay in `ws`, see prop_backward_fold_raw)."""
     B, _, H, W = dem.shape
     lib = _lib.load()
     _lib.check(lib.jspsr_prop_backward_f32(grad_out.data_ptr(), dem.data_ptr(), weight.data_ptr(), offset.data_ptr(),
                                            offset.shape[1], w.data_ptr(), gweight.data_ptr(), goffset.data_ptr(),
-                                           gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), B, H, W, _stream()),
+                                           gw.data_ptr() if gw is not None else None,
+                                           gb.data_ptr() if gb is not None else None, ws.data_ptr(), B, H, W, _stream()),
                "jspsr_prop_backward_f32")
+
+
+def prop_backward_fold_raw(ws, B, H, W, gw, gb):
+    _lib.check(_lib.load().jspsr_prop_backward_fold_f32(ws.data_ptr(), B, H, W, gw.data_ptr(), gb.data_ptr(), _stream()),
+               "jspsr_prop_backward_fold_f32")
 
 
 def prop_backward_workspace(B, H, W, device):

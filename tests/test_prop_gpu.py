@@ -191,3 +191,30 @@ def test_full_size_properties():
     ref = R.propagate(dem.cpu().double(), weight.detach().cpu().double(), off18.detach().cpu().double(),
                       w.detach().cpu().double(), b.detach().cpu().double())
     _close(o1.detach().cpu()[sl], ref[sl], 1e-5, 3e-5, "sub-block")  # fp32 coordinates at |p| ~ 500 px
+
+
+def test_backward_split_into_stream_and_fold():
+    """jspsr_prop_backward_f32 with grad_wk = grad_b0 = NULL launches only the streaming kernel; the fold entry
+    point finishes the job from the workspace -- bit-identical to the single call."""
+    from jspsr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 40, 72
+    dem = torch.rand(B, 1, H, W, generator=g).cuda()
+    wt = torch.sigmoid(torch.randn(B, 9, H, W, generator=g)).cuda()
+    off = (1.5 * torch.randn(B, 16, H, W, generator=g)).cuda()
+    wk = torch.randn(1, 1, 3, 3, generator=g).cuda()
+    go = torch.randn(B, 1, H, W, generator=g).cuda()
+    outs = []
+    for split in (False, True):
+        gw_, go_ = torch.empty_like(wt), torch.empty_like(off)
+        gk, gb = torch.full_like(wk, 7.0), torch.full((1,), 7.0, device="cuda")
+        ws = ops.prop_backward_workspace(B, H, W, "cuda")
+        if split:
+            ops.prop_backward_raw(go, dem, wt, off, wk, gw_, go_, None, None, ws)
+            assert (gk == 7).all() and (gb == 7).all()          # untouched until the fold
+            ops.prop_backward_fold_raw(ws, B, H, W, gk, gb)
+        else:
+            ops.prop_backward_raw(go, dem, wt, off, wk, gw_, go_, gk, gb, ws)
+        outs.append((gw_, go_, gk, gb))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
