@@ -18,10 +18,11 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes: int = 64 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes: int = 64 << 20, process_group=None, world=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # `world` overrides the process group's size (tests drive the bucket bookkeeping without a second rank)
+        self.world = world if world is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         total = sum(p.numel() for p in self.params)
         p0 = self.params[0]
         self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
@@ -43,6 +44,7 @@ class GradReducer:
         if count:
             self.buckets.append((start, off, count))
         self._pending = [0] * len(self.buckets)
+        self._seen = set()
         self._works = []
         if self.world > 1:
             for p in self.params:
@@ -59,9 +61,16 @@ class GradReducer:
         """Gradients alias the flat buffer: zero it in one kernel, keep the aliases."""
         self.flat.zero_()
         self._pending = [b[2] for b in self.buckets]
+        self._seen = set()
         self._works = []
 
     def _hook(self, p):
+        # A parameter reports once per step.  Kernels that write a gradient straight into the flat buffer report by
+        # hand (ops._wgrad_into / _bn_ready); depending on the PyTorch version autograd's post-accumulate hook fires
+        # for such a parameter as well (its node runs with an undefined gradient) -- the second report is dropped.
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         i = self._bucket_of[p]
         self._pending[i] -= 1
         if self._pending[i] == 0:

@@ -125,3 +125,41 @@ def test_weight_gradients_straight_into_the_flat_buffer():
         red.finish()
         for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
             assert pb.grad.data_ptr() >= red.flat.data_ptr() and torch.equal(pa.grad, pb.grad), n
+
+
+def test_bucket_bookkeeping_with_direct_gradients(monkeypatch):
+    """Data-parallel path: every bucket's all-reduce must be issued exactly once per step, after the last
+    gradient of the bucket has been produced -- whether that gradient arrived through autograd's accumulation hook
+    (biases, propagation parameters) or was written straight into the flat buffer by a kernel (conv weights,
+    BatchNorm scale/shift).  The collective is stubbed; a second rank is not needed to check the counting."""
+    import torch.distributed as dist
+    from jspsr_amd.JSPSR import Model
+    from jspsr_amd.ddp import GradReducer
+    torch.manual_seed(0)
+    m = Model(dict(MSK, COP30=1), num_feature=8).cuda()
+    calls = []
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        calls.append((t.data_ptr(), t.numel(), [p for p in red._pending]))
+        return _Work()
+
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    red = GradReducer(m.parameters(), bucket_bytes=256 << 10, world=2)   # several buckets
+    assert len(red.buckets) > 3
+    inputs, _ = R.synthetic_batch(2, 32, 64, True, seed=5, dtype=torch.float32)
+    inputs = [t.cuda() for t in inputs]
+    for _ in range(2):
+        calls.clear()
+        red.zero_grad()
+        m(*inputs).mean().backward()
+        assert len(calls) == len(red.buckets), "every bucket reduced during backward, none left for finish()"
+        assert all(v == 0 for v in red._pending)
+        es = red.flat.element_size()
+        got = sorted(((ptr - red.flat.data_ptr()) // es, n) for ptr, n, _ in calls)
+        assert got == sorted((s, e - s) for s, e, _ in red.buckets)
+        red.finish()
+        assert len(calls) == len(red.buckets)
