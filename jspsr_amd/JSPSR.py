@@ -144,6 +144,7 @@ class Model(nn.Module):
         B, H, W = dem_a.shape[:3]
         nb, nf2 = len(order), self.conv0.conv[0].out_channels
         bufs, fused, joined = [], [], []
+        defer_skip = all(getattr(self, f"layer{s}_dem")[0].fused for s in (2, 3, 4))
         for s in range(1, 5):
             planes = nf2 * 2 ** (s - 1)
             if s > 1:
@@ -152,11 +153,17 @@ class Model(nn.Module):
             buf = E.SliceBuffer(B, H, W, lead + nb * planes, dem_a.dtype, dem_a.device)
             nxt = {}
             for i, br in enumerate(order):
-                src = fused[-1] if (br == "dem" and fused) else feats[br]
-                units = getattr(self, f"layer{s}_{br}")
-                for u in list(units)[:-1]:
-                    src = u(src)
-                nxt[br] = units[-1](src, dest=(buf, lead + i * planes))
+                from_fused = br == "dem" and bool(fused)
+                src = fused[-1] if from_fused else feats[br]
+                units = list(getattr(self, f"layer{s}_{br}"))
+                for k, u in enumerate(units):
+                    kw = {}
+                    if k == 0 and from_fused and defer_skip:
+                        kw["grad_extra"] = bufs[-1][0]      # the decoder's gradient of fused[s-1] is parked there
+                    if k == len(units) - 1:
+                        kw["dest"] = (buf, lead + i * planes)
+                    src = u(src, **kw)
+                nxt[br] = src
             feats = nxt
             bufs.append((buf, lead))
             joined.append([feats[b] for b in order])
@@ -164,7 +171,10 @@ class Model(nn.Module):
         x = fused[3]
         for up, s in ((self.layer3d, 2), (self.layer2d, 1), (self.layer1d, 0)):
             buf, lead = bufs[s]
-            x = buf.join([up(x, dest=(buf, 0))] + joined[s], 0)  # cat((up, skip)), :354-368
+            # cat((up, skip)), :354-368.  fused[s] has two consumers (this decoder stage and the next encoder stage's
+            # dem branch): the decoder's share of its gradient is parked in the buffer and added inside that branch's
+            # first block (grad_extra above) instead of by autograd
+            x = buf.join([up(x, dest=(buf, 0))] + joined[s], 0, defer=nb if defer_skip else 0)
         c0 = self.conv0(x)
         dem = dem.detach()  # :372
         weight, off16 = self.generator.heads(self.generator.features(dem_a.detach(), c0))

@@ -81,10 +81,12 @@ class ResUnit(nn.Module):
 
     fused = True   # one autograd node per block (ops._ResUnit); False = the op-by-op composition below
 
-    def forward(self, x, dest=None):
+    def forward(self, x, dest=None, grad_extra=None):
         if self.fused:
             return E.res_unit(x, self.conv1, self.bn1, self.conv2, self.bn2, self.downsample, self.stride, self.scale,
-                              self.act, dest)
+                              self.act, dest, grad_extra)
+        if grad_extra is not None:
+            raise RuntimeError("grad_extra needs the fused block")
         y = E.conv_bn(x, self.conv1.weight, self.bn1, self.stride, 1, relu=True)
         if self.downsample is not None:
             r = E.conv_bn(x, self.downsample[0].weight, self.downsample[1], self.stride, 0)

@@ -129,7 +129,7 @@ def _bn_state(bn: torch.nn.BatchNorm2d):
     return (bn.running_mean, bn.running_var, bn.momentum, bn.eps, training)
 
 
-def res_unit(x, conv1, bn1, conv2, bn2, downsample, stride, scale, act, dest=None):
+def res_unit(x, conv1, bn1, conv2, bn2, downsample, stride, scale, act, dest=None, grad_extra=None):
     """BasicBlock (basics.py:88-123) as one autograd node (ops._ResUnit)."""
     bns = [_bn_state(bn1), _bn_state(bn2)]
     wd = gd = bd = None
@@ -137,7 +137,7 @@ def res_unit(x, conv1, bn1, conv2, bn2, downsample, stride, scale, act, dest=Non
         wd, gd, bd = downsample[0].weight, downsample[1].weight, downsample[1].bias
         bns.append(_bn_state(downsample[1]))
     return ops.res_unit(x, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias, wd, gd, bd,
-                        stride, scale, act, tuple(bns), dest)
+                        stride, scale, act, tuple(bns), dest, grad_extra)
 
 
 def channel_gate(x, w1, w2):

@@ -160,6 +160,11 @@ class SliceBuffer:
 
     def __init__(self, B, H, W, C, dtype, device):
         self.buf = torch.empty((B, H, W, C), dtype=dtype, device=device)
+        self.deferred = None     # see join(defer=...)
+
+    def take_deferred(self):
+        g, self.deferred = self.deferred, None
+        return g
 
     def slice(self, lo, n, shape=None):
         """The (B,H,W,n) channel slice starting at `lo`; `shape` = the (B,H,W) the producer is about to write."""
@@ -172,14 +177,20 @@ class SliceBuffer:
             raise ValueError("SliceBuffer: slice start / buffer width must be a multiple of 16 bytes")
         return v
 
-    def join(self, parts, lo=0):
-        """parts: the tensors returned by the producers, in channel order starting at `lo`."""
-        return _Join.apply(self, lo, *parts)
+    def join(self, parts, lo=0, defer=0):
+        """parts: the tensors returned by the producers, in channel order starting at `lo`.
+        defer = n: the gradient of the LAST n parts is not returned to them by this join; it is parked in
+        `self.deferred` (a channel-slice view of the incoming gradient) for the other consumer of those parts -- a
+        `res_unit(..., grad_extra=self)` that reads the same slices through another join and runs later in the
+        backward pass -- to add in its data-gradient epilogue.  The two gradients of a tensor with two consumers then
+        meet inside that kernel instead of in an extra pass over the tensor."""
+        return _Join.apply(self, lo, defer, *parts)
 
 
 class _Join(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, holder, lo, *parts):
+    def forward(ctx, holder, lo, defer, *parts):
+        ctx.holder, ctx.defer = holder, int(defer)
         ctx.widths = [p.shape[3] for p in parts]
         n = sum(ctx.widths)
         for p, w in zip(parts, ctx.widths):   # the producers must really have written into this buffer
@@ -190,10 +201,13 @@ class _Join(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         outs, off = [], 0
-        for w in ctx.widths:
-            outs.append(g.narrow(3, off, w))
+        keep = len(ctx.widths) - ctx.defer
+        for i, w in enumerate(ctx.widths):
+            outs.append(g.narrow(3, off, w) if i < keep else None)
+            if i == keep:
+                ctx.holder.deferred = g.narrow(3, off, sum(ctx.widths[keep:]))
             off += w
-        return (None, None) + tuple(outs)
+        return (None, None, None) + tuple(outs)
 
 
 class _Conv(torch.autograd.Function):
@@ -340,7 +354,8 @@ class _ResUnit(torch.autograd.Function):
     the autograd engine drops from 5-8 to 1."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest, grad_extra=None):
+        ctx.grad_extra = grad_extra
         x = K.nhwc(x)
         cdt, e = x.dtype, K.epc(x.dtype)
         B, H, W, Cp = x.shape
@@ -407,22 +422,31 @@ class _ResUnit(torch.autograd.Function):
         dW1 = _wgrad_into(p1, dz1, x, O, Cin, 3, 3, stride, 1)
         dWd = dgd = dbd = None
         side = dres                      # what reaches x along the shortcut
+        # gradient of x parked by its other consumer (SliceBuffer.join(defer=...)): rides along as an addend too
+        extra = ctx.grad_extra.take_deferred() if ctx.grad_extra is not None else None
+        if extra is not None:
+            extra = K.nhwc(extra)
+            if tuple(extra.shape) != tuple(x.shape):
+                raise RuntimeError(f"res_unit: deferred gradient {tuple(extra.shape)} does not match the input {tuple(x.shape)}")
+            if not (has_d and need_x):
+                side, extra = side + extra, None
         if has_d:
             sinkd = _bn_sink(pgd, pbd)
             dzd, _, dgd, dbd = K.bn_backward(dres, None, zd, gd, md, idd, trd, 0, 1.0, beta=bd, grads_into=sinkd)
             if sinkd is not None:
                 _bn_ready(pgd, pbd)
             dWd = _wgrad_into(pd, dzd, x, O, Cin, 1, 1, stride, 0)
-            side = K.conv2d_dgrad(dzd, K.pack_weight(wd, 1, O, cdt), (H, W), stride, 0) if need_x else None
+            side = K.conv2d_dgrad(dzd, K.pack_weight(wd, 1, O, cdt), (H, W), stride, 0, addend=extra) if need_x else None
         dx = None
         if need_x:
             dx = K.conv2d_dgrad(dz1, K.pack_weight(w1, 1, O, cdt), (H, W), stride, 1, addend=K.nhwc(side))
-        return (dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None, None, None, None)
+        return (dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None, None, None, None, None)
 
 
-def res_unit(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest=None):
-    """bns: ((running_mean, running_var, momentum, eps, training), ...) for bn1, bn2[, downsample bn]."""
-    return _ResUnit.apply(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest)
+def res_unit(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest=None, grad_extra=None):
+    """bns: ((running_mean, running_var, momentum, eps, training), ...) for bn1, bn2[, downsample bn].
+    grad_extra: a SliceBuffer whose `deferred` gradient (see SliceBuffer.join) belongs to `x`."""
+    return _ResUnit.apply(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest, grad_extra)
 
 
 def _gate_mlp(avg, mx, w1, w2):

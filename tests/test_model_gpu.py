@@ -163,3 +163,30 @@ def test_bucket_bookkeeping_with_direct_gradients(monkeypatch):
         assert got == sorted((s, e - s) for s, e, _ in red.buckets)
         red.finish()
         assert len(calls) == len(red.buckets)
+
+
+def test_block_level_autograd_node_equals_op_by_op_graph():
+    """ResUnit.fused (one autograd node per BasicBlock, shortcut and parked skip gradients added inside the conv1
+    data-gradient kernel) against the op-by-op graph where autograd performs those additions: the forward is the
+    same kernel sequence (bit-identical), so every gradient may differ only by the order of a few additions."""
+    from jspsr_amd.JSPSR import Model
+    from jspsr_amd.blocks import ResUnit
+    torch.manual_seed(0)
+    ic = dict(MSK, COP30=1)
+    m = Model(ic, num_feature=8).cuda()
+    inputs, _ = R.synthetic_batch(2, 32, 64, True, seed=9, dtype=torch.float32)
+    inputs = [t.cuda() for t in inputs]
+    probe = R.probe_gradient((2, 1, 32, 64), 3, torch.float32).cuda()
+    res = []
+    for fused in (True, False):
+        ResUnit.fused = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            out = m(*inputs)
+            (out * probe).mean().backward()
+            res.append((out.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+        finally:
+            ResUnit.fused = True
+    assert torch.equal(res[0][0], res[1][0])
+    worst = max(_rel(res[0][1][n], res[1][1][n]) for n in res[0][1])
+    assert worst < 2e-5, worst
