@@ -100,11 +100,15 @@ int jspsr_pack_weight(int dtype, const float* w, void* packed, int O, int I, int
  * statistics of the result taken from the fp32 accumulators -- jspsr_conv2d_stats_rows(B,OH,OW) partial
  * rows of [sum over the row's pixels | sum of squares] x Cout floats, to be handed to jspsr_bn_forward
  * (ext_partial / ext_rows), which then skips its own pass over the tensor. */
+/* Inference epilogue (all optional, NULL = absent): out = [relu](acc * scale[c] + bias[c] + addend), the ReLU always
+ * last.  With scale/bias from jspsr_bn_fold and addend = the shortcut tensor this is conv -> BatchNorm(eval)
+ * (-> + residual) (-> ReLU) of basics.py:49-53,111-123 in one launch.  Not combinable with `stats`. */
 int jspsr_conv2d_stats_rows(int B, int OH, int OW);
 int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const float* bias, void* out,
                          int B, int IH, int IW, int Cin, int in_cstride, int in_coff, int Cout,
                          int out_cstride, int out_coff, int KH, int KW, int stride, int pad, int relu,
-                         float* stats, jspsr_stream_t stream);
+                         float* stats, const float* scale, const void* addend, int add_cstride,
+                         jspsr_stream_t stream);
 
 /* gin[b,y,x,c] = bias[c] + sum_{ky,kx,n} gout[b,(y+pad-ky)/stride,(x+pad-kx)/stride,n] * W[n,c,ky,kx]
  * over the taps where the division is exact: the data gradient of the conv above, and equally
@@ -153,6 +157,11 @@ int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, const void*
                      float* running_mean, float* running_var, float momentum, float eps, int training,
                      int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
                      const float* ext_partial, int ext_rows, void* workspace, jspsr_stream_t stream);
+
+/* BatchNorm in eval mode as a per-channel affine: scale = gamma / sqrt(var + eps) * res_scale,
+ * shift = (beta - mean * gamma / sqrt(var + eps)) * res_scale. */
+int jspsr_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                  float eps, float res_scale, int C, float* scale, float* shift, jspsr_stream_t stream);
 
 /* Backward of the above.  dy is the gradient w.r.t. y.  relu: 0 = none; 1 = mask from the saved output
  * (y > 0); 2 = mask recomputed from x as gamma*xhat + beta > 0 (valid without a residual; y is not read).

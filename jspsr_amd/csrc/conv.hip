@@ -105,6 +105,24 @@ __device__ __forceinline__ uint4 add_packed(uint4 a, uint4 b) {
   }
 }
 
+// max(x, 0) on 16 bytes of T
+template <typename T>
+__device__ __forceinline__ uint4 relu_packed(uint4 a) {
+  if constexpr (sizeof(T) == 4) {
+    float4 x = __builtin_bit_cast(float4, a);
+    x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+    return __builtin_bit_cast(uint4, x);
+  } else {
+    unsigned* p = &a.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {           // bf16: sign bit set -> negative (or -0) -> 0
+      if (p[i] & 0x00008000u) p[i] &= 0xffff0000u;
+      if (p[i] & 0x80000000u) p[i] &= 0x0000ffffu;
+    }
+    return a;
+  }
+}
+
 // UNI: Cin is a multiple of the stage depth BK, so every 16-byte chunk of a stage belongs to the
 // same tap -> the tap walk is wave-uniform (scalar registers, scalar offset of the buffer loads).
 // NBUF: LDS staging buffers.  2 = one barrier per stage; 1 = two barriers per stage but half the LDS,
@@ -332,12 +350,14 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
     if (NBUF == 1) __syncthreads();
     stats_epilogue<MI, NI, WGM, WTM, WTN, BN>(acc, stats, smem, mt, g.Cout, n0, wm, wn, lr, lh, out_pixel);
   }
-  float bv[NI];
+  float bv[NI], sv[NI];
   int ncol[NI];
+  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend;   // ReLU is the last operation
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     ncol[ni] = n0 + wn * WTN + ni * 32 + lr;
     bv[ni] = (bias && ncol[ni] < g.Cout) ? bias[ncol[ni]] : 0.f;
+    sv[ni] = (g.scale && ncol[ni] < g.Cout) ? g.scale[ncol[ni]] : 1.f;
   }
   constexpr int OPITCH = BN * (int)sizeof(T) + 16;       // bytes per staged output row (+16: bank spread)
   // the launcher sizes dynamic LDS as max(staging, BM * OPITCH)
@@ -376,8 +396,8 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
         const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          float v = acc[mi][ni][e] + bv[ni];
-          if (g.relu) v = fmaxf(v, 0.f);
+          float v = acc[mi][ni][e] * sv[ni] + bv[ni];
+          if (relu_first) v = fmaxf(v, 0.f);
           *reinterpret_cast<T*>(Os + row * OPITCH + (wn * WTN + ni * 32 + lr) * (int)sizeof(T)) = (T)v;
         }
       }
@@ -395,6 +415,7 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
       else if (g.addend)
         v = add_packed<T>(v, *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
                                                               (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16));
+      if (relu_last) v = relu_packed<T>(v);
       *reinterpret_cast<uint4*>(obase + opix * g.out_cstride * (long long)sizeof(T) + c16 * 16) = v;
     }
   } else {
@@ -409,9 +430,10 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           if (ncol[ni] >= g.Cout) continue;
-          float v = acc[mi][ni][e] + bv[ni];
-          if (g.relu) v = fmaxf(v, 0.f);
+          float v = acc[mi][ni][e] * sv[ni] + bv[ni];
+          if (relu_first) v = fmaxf(v, 0.f);
           if (g.addend) v = (float)(T)v + (float)static_cast<const T*>(g.addend)[opix * g.add_cstride + ncol[ni]];
+          if (relu_last) v = fmaxf(v, 0.f);
           orow[ncol[ni]] = (T)v;
         }
       }
@@ -639,12 +661,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
       stats_epilogue<MI, NI, WGM, WTM, WTN, BN>(acc, stats, smem, r1, g.Cout, n0, wm, wn, lr, lh, out_pixel, r2);
     }
   }
-  float bv[NI];
+  float bv[NI], sv[NI];
   int ncol[NI];
+  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend;   // ReLU is the last operation
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     ncol[ni] = n0 + wn * WTN + ni * 32 + lr;
     bv[ni] = (bias && ncol[ni] < g.Cout) ? bias[ncol[ni]] : 0.f;
+    sv[ni] = (g.scale && ncol[ni] < g.Cout) ? g.scale[ncol[ni]] : 1.f;
   }
   constexpr int OPITCH = BN * (int)sizeof(T) + 16;
   char* Os = smem;
@@ -681,8 +705,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
         const int row = wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          float v = acc[mi][ni][e] + bv[ni];
-          if (g.relu) v = fmaxf(v, 0.f);
+          float v = acc[mi][ni][e] * sv[ni] + bv[ni];
+          if (relu_first) v = fmaxf(v, 0.f);
           *reinterpret_cast<T*>(Os + row * OPITCH + (wn * WTN + ni * 32 + lr) * (int)sizeof(T)) = (T)v;
         }
       }
@@ -699,6 +723,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
       else if (g.addend)
         v = add_packed<T>(v, *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
                                                               (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16));
+      if (relu_last) v = relu_packed<T>(v);
       *reinterpret_cast<uint4*>(obase + opix * g.out_cstride * (long long)sizeof(T) + c16 * 16) = v;
     }
   } else {
@@ -713,9 +738,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           if (ncol[ni] >= g.Cout) continue;
-          float v = acc[mi][ni][e] + bv[ni];
-          if (g.relu) v = fmaxf(v, 0.f);
+          float v = acc[mi][ni][e] * sv[ni] + bv[ni];
+          if (relu_first) v = fmaxf(v, 0.f);
           if (g.addend) v = (float)(T)v + (float)static_cast<const T*>(g.addend)[opix * g.add_cstride + ncol[ni]];
+          if (relu_last) v = fmaxf(v, 0.f);
           orow[ncol[ni]] = (T)v;
         }
       }
@@ -863,8 +889,10 @@ extern "C" int jspsr_conv2d_stats_rows(int B, int OH, int OW) {
 extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const float* bias, void* out,
                                     int B, int IH, int IW, int Cin, int in_cstride, int in_coff, int Cout,
                                     int out_cstride, int out_coff, int KH, int KW, int stride, int pad, int relu,
-                                    float* stats, jspsr_stream_t stream) {
+                                    float* stats, const float* scale, const void* addend, int add_cstride,
+                                    jspsr_stream_t stream) {
   if (int e = check_common(dtype, in, wpack, out, Cin, in_cstride, in_coff, out_cstride, out_coff, Cout, "conv2d_forward")) return e;
+  if (addend && add_cstride < Cout) return fail(JSPSR_EINVAL, "conv2d_forward: addend pitch %d < %d channels", add_cstride, Cout);
   if (B <= 0 || IH <= 0 || IW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     return fail(JSPSR_EINVAL, "conv2d_forward: bad geometry");
   ConvGeom g{};
@@ -879,7 +907,9 @@ extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack
   g.oy_mul = 1; g.oy_add = 0; g.ox_mul = 1; g.ox_add = 0; g.relu = relu;
   g.accumulate = getenv("JSPSR_CONV_NOXCD") ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (stats && (bias || relu)) return fail(JSPSR_EINVAL, "conv2d_forward: statistics are taken from the raw accumulators (no bias / ReLU)");
+  if (stats && (bias || relu || scale || addend))
+    return fail(JSPSR_EINVAL, "conv2d_forward: statistics are taken from the raw accumulators (no bias / scale / addend / ReLU)");
+  g.scale = scale; g.addend = addend; g.add_cstride = add_cstride;
   return dtype == JSPSR_F32 ? launch<float>(in, wpack, bias, out, stats, g, s) : launch<__bf16>(in, wpack, bias, out, stats, g, s);
 }
 

@@ -44,8 +44,9 @@ struct ConvGeom {
   int oy_mul, oy_add, ox_mul, ox_add;
   int relu;               // epilogue ReLU
   int accumulate;         // lab switch (JSPSR_CONV_NOXCD)
-  const void* addend;     // optional tensor on the written grid, added after bias/ReLU: out = [relu](acc + bias) + addend
+  const void* addend;     // optional tensor on the written grid: out = [relu](acc * scale + bias + addend)
   int add_cstride;        // its channel pitch (channel 0 of the addend = channel out_coff of the written slice)
+  const float* scale;     // optional per-output-channel factor (inference: BatchNorm folded into the epilogue)
 };
 
 }  // namespace jspsr

@@ -247,6 +247,18 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int rows, 
   shift[c] = beta[c] - mean * sc;
 }
 
+// inference: BatchNorm as a per-channel affine, y = x * scale + shift (optionally times res_scale), for folding into a
+// convolution's epilogue
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps, float res_scale,
+                               int C, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] * (1.0f / sqrtf(var[c] + eps));
+  scale[c] = sc * res_scale;
+  shift[c] = (beta[c] - mean[c] * sc) * res_scale;
+}
+
 // y = [relu]( (x*scale + shift) * res_scale + res )
 template <typename T>
 __global__ __launch_bounds__(TX * TY) void bn_apply_kernel(const T* __restrict__ x, int x_cs, int x_coff,
@@ -626,6 +638,15 @@ extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_co
                                      static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, coef, relu,
                                      static_cast<T*>(dx), static_cast<T*>(dres), g));
   return check_launch("bn_bwd_apply");
+}
+
+extern "C" int jspsr_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                             float eps, float res_scale, int C, float* scale, float* shift, jspsr_stream_t stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0)
+    return fail(JSPSR_EINVAL, "bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gamma, beta,
+                     running_mean, running_var, eps, res_scale, C, scale, shift);
+  return check_launch("bn_fold");
 }
 
 extern "C" int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int relu,

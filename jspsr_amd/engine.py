@@ -120,6 +120,9 @@ def conv_bn(x, weight, bn: torch.nn.BatchNorm2d, stride=1, padding=0, relu=False
     if bn.training or bn.running_mean is None:
         y, st = ops.conv2d_with_stats(x, weight, stride, padding)
         return batch_norm(y, bn, relu, residual, res_scale, partial=st, dest=dest)
+    if not torch.is_grad_enabled():     # inference: BatchNorm folded into the conv epilogue, one launch
+        return ops.conv_bn_infer(x, weight, bn.weight, bn.bias, _bn_state(bn), stride, padding, relu, residual,
+                                 res_scale, dest)
     return batch_norm(ops.conv2d(x, weight, None, stride, padding), bn, relu, residual, res_scale, dest=dest)
 
 

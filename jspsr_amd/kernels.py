@@ -77,10 +77,12 @@ def pack_weight(w: torch.Tensor, mode: int, c_pad: int, dtype: torch.dtype) -> t
     return out
 
 
-def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0, cin=None, in_coff=0, stats=False):
+def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0, cin=None, in_coff=0, stats=False,
+                   scale=None, addend=None):
     """x (B,IH,IW,Cs) NHWC, wpack [Cout][KH][KW][Cin] -> (B,OH,OW,Cout) (or a slice of `out`).
     stats=True (no bias / ReLU): also returns the BatchNorm partial statistics (rows, 2, Cout) fp32 taken from
-    the accumulators in the epilogue."""
+    the accumulators in the epilogue.  scale (Cout,) fp32 / addend (B,OH,OW,Cout): inference epilogue
+    out = [relu](acc * scale + bias + addend)."""
     _chk_s(x, "conv2d_forward")
     B, IH, IW, _ = x.shape
     Cs = pitch(x)
@@ -95,10 +97,17 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
     st = None
     if stats:
         st = torch.empty((lib.jspsr_conv2d_stats_rows(B, OH, OW), 2, Cout), dtype=torch.float32, device=x.device)
+    if addend is not None:
+        _chk_s(addend, "conv2d_forward addend")
+        if tuple(addend.shape) != (B, OH, OW, Cout) or addend.dtype != x.dtype:
+            raise ValueError(f"conv2d_forward: addend {tuple(addend.shape)} {addend.dtype} does not match the result")
     _lib.check(lib.jspsr_conv2d_forward(_dt(x), x.data_ptr(), wpack.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                         B, IH, IW, Cin, Cs, in_coff, Cout, pitch(out), out_coff,
                                         KH, KW, stride, pad, int(relu), st.data_ptr() if st is not None else None,
+                                        scale.data_ptr() if scale is not None else None,
+                                        addend.data_ptr() if addend is not None else None,
+                                        pitch(addend) if addend is not None else 0,
                                         _stream()), "jspsr_conv2d_forward")
     return (out, st) if stats else out
 
@@ -192,6 +201,17 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
                                     partial.shape[0] if partial is not None else 0, ws.data_ptr(), _stream()),
                "jspsr_bn_forward")
     return out, mean, invstd
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps, res_scale=1.0):
+    """Eval-mode BatchNorm as (scale, shift) fp32 vectors for a conv epilogue."""
+    C = gamma.numel()
+    scale = torch.empty(C, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    _lib.check(_lib.load().jspsr_bn_fold(gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                         float(eps), float(res_scale), C, scale.data_ptr(), shift.data_ptr(), _stream()),
+               "jspsr_bn_fold")
+    return scale, shift
 
 
 def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False, beta=None,

@@ -443,9 +443,36 @@ class _ResUnit(torch.autograd.Function):
         return (dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None, None, None, None, None)
 
 
+def conv_bn_infer(x, weight, gamma, beta, bn, stride, pad, relu=False, res=None, res_scale=1.0, dest=None):
+    """Inference (no autograd, BatchNorm on its running statistics): conv -> BN (-> * res_scale + res) (-> ReLU) as
+    ONE launch -- the normalisation is a per-channel affine folded into the conv epilogue, the shortcut is its addend.
+    bn = (running_mean, running_var, momentum, eps, training)."""
+    x = K.nhwc(x)
+    rm, rv, _, eps, training = bn
+    if training or rm is None:
+        raise RuntimeError("conv_bn_infer: BatchNorm must be in eval mode with running statistics")
+    sc, sh = K.bn_fold(gamma.detach(), beta.detach(), rm, rv, eps, res_scale if res is not None else 1.0)
+    O, I, KH, KW = weight.shape
+    B, H, W, Cp = x.shape
+    out = None
+    if dest is not None:
+        out = dest[0].slice(dest[1], O, (B, (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1))
+    return K.conv2d_forward(x, K.pack_weight(weight.detach().contiguous(), 0, Cp, x.dtype), sh, stride, pad, relu, out=out,
+                            scale=sc, addend=K.nhwc(res) if res is not None else None)
+
+
+def res_unit_infer(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest=None):
+    """BasicBlock in inference mode: three (two without projection) launches, nothing else touches the tensors."""
+    y1 = conv_bn_infer(x, w1, g1, b1, bns[0], stride, 1, relu=True)
+    r = conv_bn_infer(x, wd, gd, bd, bns[2], stride, 0) if wd is not None else x
+    return conv_bn_infer(y1, w2, g2, b2, bns[1], 1, 1, relu=bool(act), res=r, res_scale=scale, dest=dest)
+
+
 def res_unit(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest=None, grad_extra=None):
     """bns: ((running_mean, running_var, momentum, eps, training), ...) for bn1, bn2[, downsample bn].
     grad_extra: a SliceBuffer whose `deferred` gradient (see SliceBuffer.join) belongs to `x`."""
+    if not torch.is_grad_enabled() and not any(b[4] for b in bns):
+        return res_unit_infer(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest)
     return _ResUnit.apply(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest, grad_extra)
 
 

@@ -218,6 +218,48 @@ def test_conv_dgrad_addend(dtype, B, H, W, Cin, Cout, k, stride, pad):
     assert torch.equal(fused, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,with_res,relu", [
+    (2, 24, 40, 64, 64, 3, 1, 1, True, True),      # BasicBlock tail: conv2 -> bn2 -> + shortcut -> ReLU
+    (1, 40, 36, 64, 128, 3, 1, 1, False, True),    # conv1 -> bn1 -> ReLU
+    (2, 16, 16, 64, 128, 1, 2, 0, False, False),   # projection shortcut: conv1x1 s2 -> bn
+    (1, 17, 19, 8, 200, 3, 1, 1, True, True),      # partly filled N tile
+    (1, 12, 12, 32, 9, 1, 1, 0, True, True),       # scalar epilogue (9 channels)
+    (4, 256, 256, 64, 64, 3, 1, 1, True, True),    # 16x16-pixel tile instantiation
+])
+def test_conv_inference_epilogue(dtype, B, H, W, Cin, Cout, k, stride, pad, with_res, relu):
+    """out = [relu](conv(x) * scale + shift (+ addend)) with (scale, shift) = eval-mode BatchNorm folded by
+    jspsr_bn_fold: the reference's conv -> BatchNorm2d.eval() (-> + residual) (-> ReLU), basics.py:49-53,111-123."""
+    K = _k()
+    if Cin % K.epc(dtype):
+        pytest.skip("channel granularity")
+    g = torch.Generator().manual_seed(B * 5 + H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    gamma, beta = 1 + 0.3 * torch.randn(Cout, generator=g), 0.2 * torch.randn(Cout, generator=g)
+    rm, rv = 0.3 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, OH, OW, generator=g) if with_res else None
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+        res = res.bfloat16().float() if res is not None else None
+    rs = 0.5 if with_res else 1.0
+    ref = F.batch_norm(F.conv2d(x.double(), w.double(), None, stride, pad), rm.double(), rv.double(), gamma.double(),
+                       beta.double(), False, 0.1, 1e-5)
+    if res is not None:
+        ref = ref * rs + res.double()
+    if relu:
+        ref = F.relu(ref)
+    sc, sh = K.bn_fold(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5, rs)
+    resd = _nhwc(res).to(dtype) if res is not None else None
+    y = K.conv2d_forward(_nhwc(x).to(dtype), K.pack_weight(w.cuda(), 0, Cin, dtype), sh, stride, pad, relu,
+                         scale=sc, addend=resd)
+    tol = 3e-6 if dtype == torch.float32 else 8e-3
+    assert _relerr(_nchw(y.float()), ref) < tol
+    if relu:
+        assert (y >= 0).all()
+
+
 def test_conv_transpose_wgrad():
     """ConvTranspose2d weight (I,O,kh,kw): G = its input, X = grad of its output."""
     K = _k()

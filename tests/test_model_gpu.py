@@ -51,6 +51,15 @@ def test_model_matches_reference_fixture(golden_dir, name, ic):
     ref = torch.from_numpy(z["pred"])
     assert (pred.detach().cpu().double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
     if not training:
+        # inference path proper: under no_grad every conv -> BatchNorm(eval) (-> + shortcut) (-> ReLU) is one launch
+        # with the normalisation folded into the conv epilogue (ops.conv_bn_infer) -- same bound, fp32 and bf16
+        with torch.no_grad():
+            pred_i = m(*inputs)
+        assert (pred_i.cpu().double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+        m.compute_dtype = torch.bfloat16
+        with torch.no_grad():
+            pred_b = m(*inputs)
+        assert (pred_b.cpu().double() - ref).abs().max().item() < 3e-2 * ref.abs().max().item()
         return
     loss = (pred - gt).abs().mean() + ((pred - gt) ** 2).mean()
     assert abs(loss.item() - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
