@@ -52,6 +52,10 @@ def test_lrru(golden_dir, name):
     m.load_state_dict(sd)
     m = m.cuda().train(bool(z["training"]))
     _check(z, m, m(*inputs), gt)
+    if not bool(z["training"]):
+        # inference path (BatchNorm folded into the conv epilogues, ops.conv_bn_infer): same bound
+        with torch.no_grad():
+            _check(z, m, m(*inputs), gt)
 
 
 def test_edsr(golden_dir):
