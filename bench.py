@@ -192,6 +192,7 @@ def main():
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     broadcast_module(model)
     reducer = GradReducer(model.parameters())
+    reducer.watch_streams(model.side_streams(device))
     opt = FlatAdamW(reducer, lr=1e-3, weight_decay=1e-6)  # configs/*.yml:71-76, one fused HIP launch
     criterion = MultiLoss(1.0, 1.0, 0.1)
     inputs, gt = synthetic_batch(args.batch, TILE, TILE, device, seed=1000 + rank)

@@ -7,7 +7,9 @@ it can be handed to the reference's ``main.py`` train/eval loops and checkpoints
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -128,6 +130,24 @@ class Model(nn.Module):
         with E.compute_dtype(self.compute_dtype), E.count_batches():
             return self._forward(dem, img, aux)
 
+    branch_streams = True   # guidance branches on side streams (class-wide switch; JSPSR_BRANCH_STREAMS=0 disables)
+
+    def _side_streams(self, device):
+        """{branch: stream} for the img / aux branches on `device`, or None when disabled."""
+        if not self.branch_streams or os.environ.get("JSPSR_BRANCH_STREAMS", "1") == "0" or device.type != "cuda":
+            return None
+        cache = self.__dict__.setdefault("_branch_stream_cache", {})
+        key = (device.index if device.index is not None else torch.cuda.current_device())
+        if key not in cache:
+            cache[key] = {br: torch.cuda.Stream(device=device) for br in ("img", "aux")}
+        return {br: st for br, st in cache[key].items() if br in self._branches}
+
+    def side_streams(self, device=None):
+        """Streams the backward pass may write parameter gradients from (for GradReducer.watch_streams)."""
+        device = device if device is not None else next(self.parameters()).device
+        side = self._side_streams(torch.device(device))
+        return list(side.values()) if side else []
+
     def _forward(self, dem, img, aux):
         dem_a = E.from_nchw(dem)
         feats = {"dem": self.conv_dem(dem_a)}
@@ -152,18 +172,38 @@ class Model(nn.Module):
             lead = planes if s < 4 else 0       # room for the decoder's up-sampled features
             buf = E.SliceBuffer(B, H, W, lead + nb * planes, dem_a.dtype, dem_a.device)
             nxt = {}
+            # The branches of a stage are independent until the concat: the guidance branches run on side streams
+            # beside the dem branch (their deep-stage grids are too small to fill the chip alone).  autograd replays
+            # each node's backward on its forward stream, so the backward pass gets the same concurrency.
+            side = self._side_streams(dem_a.device) if len(order) > 1 else None
+            if side is not None:
+                main = torch.cuda.current_stream()
+                forked = main.record_event()              # everything the branches read, and `buf`, exists by now
             for i, br in enumerate(order):
                 from_fused = br == "dem" and bool(fused)
                 src = fused[-1] if from_fused else feats[br]
                 units = list(getattr(self, f"layer{s}_{br}"))
-                for k, u in enumerate(units):
-                    kw = {}
-                    if k == 0 and from_fused and defer_skip:
-                        kw["grad_extra"] = bufs[-1][0]      # the decoder's gradient of fused[s-1] is parked there
-                    if k == len(units) - 1:
-                        kw["dest"] = (buf, lead + i * planes)
-                    src = u(src, **kw)
+                st = side.get(br) if side is not None else None
+                if st is not None:
+                    st.wait_event(forked)
+                    # tensors of the main stream's allocator pool that this stream touches (now, and again in
+                    # the backward pass through saved references): tell the allocator, or it may hand their memory
+                    # out again while work queued on `st` still uses it
+                    buf.buf.record_stream(st)
+                    if s == 1:
+                        src.record_stream(st)
+                with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                    for k, u in enumerate(units):
+                        kw = {}
+                        if k == 0 and from_fused and defer_skip:
+                            kw["grad_extra"] = bufs[-1][0]      # the decoder's gradient of fused[s-1] is parked there
+                        if k == len(units) - 1:
+                            kw["dest"] = (buf, lead + i * planes)
+                        src = u(src, **kw)
                 nxt[br] = src
+            if side is not None:
+                for st in side.values():
+                    main.wait_stream(st)                  # the concat (and everything after it) sees all branches
             feats = nxt
             bufs.append((buf, lead))
             joined.append([feats[b] for b in order])

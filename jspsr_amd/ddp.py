@@ -46,6 +46,7 @@ class GradReducer:
         self._pending = [0] * len(self.buckets)
         self._seen = set()
         self._works = []
+        self._streams, self._home = [], None
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
@@ -57,8 +58,21 @@ class GradReducer:
             p._jspsr_direct_grad = True
             p._jspsr_grad_ready = self._hook if self.world > 1 else None
 
+    def watch_streams(self, streams):
+        """Side streams whose backward kernels write gradients into the flat buffer (Model.side_streams()): a
+        bucket's all-reduce is ordered after all of them, not only after the stream its last gradient came from."""
+        self._streams = list(streams)
+
+    def _join_streams(self):
+        if self.flat.is_cuda and (self._streams or self._home is not None):
+            cur = torch.cuda.current_stream()
+            for st in self._streams + ([self._home] if self._home is not None else []):
+                if st != cur:
+                    cur.wait_stream(st)
+
     def zero_grad(self):
         """Gradients alias the flat buffer: zero it in one kernel, keep the aliases."""
+        self._home = torch.cuda.current_stream() if self.flat.is_cuda else None
         self.flat.zero_()
         self._pending = [b[2] for b in self.buckets]
         self._seen = set()
@@ -75,6 +89,7 @@ class GradReducer:
         self._pending[i] -= 1
         if self._pending[i] == 0:
             s, e, _ = self.buckets[i]
+            self._join_streams()
             self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):

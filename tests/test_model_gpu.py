@@ -199,3 +199,47 @@ def test_block_level_autograd_node_equals_op_by_op_graph():
     assert torch.equal(res[0][0], res[1][0])
     worst = max(_rel(res[0][1][n], res[1][1][n]) for n in res[0][1])
     assert worst < 2e-5, worst
+
+
+@pytest.mark.parametrize("nf,B,H,W,dtype", [(8, 2, 64, 64, torch.float32), (32, 2, 256, 256, torch.bfloat16)])
+def test_branch_streams_change_nothing(nf, B, H, W, dtype):
+    """The guidance branches run on side streams beside the dem branch (forward and, through autograd's stream
+    replay, backward).  Same kernels on the same data in the same per-tensor order: outputs, every parameter
+    gradient and the BatchNorm buffers must be bit-identical to the single-stream run, on every repetition."""
+    from jspsr_amd.JSPSR import Model
+    from jspsr_amd.ddp import GradReducer
+    torch.manual_seed(0)
+    ic = dict(MSK, COP30=1)
+    ref_m = Model(ic, num_feature=nf).cuda()
+    ref_m.compute_dtype = dtype
+    state = {k: v.clone() for k, v in ref_m.state_dict().items()}
+    inputs, _ = R.synthetic_batch(B, H, W, True, seed=11, dtype=torch.float32)
+    inputs = [t.cuda() for t in inputs]
+    probe = R.probe_gradient((B, 1, H, W), 13, torch.float32).cuda()
+
+    def run(streams, direct):
+        m = Model(ic, num_feature=nf).cuda()
+        m.load_state_dict(state)
+        m.compute_dtype = dtype
+        m.branch_streams = streams
+        red = GradReducer(m.parameters()) if direct else None
+        for _ in range(2):                       # second step: allocator blocks are being recycled
+            if red is not None:
+                red.zero_grad()
+            else:
+                m.zero_grad(set_to_none=True)
+            out = m(*inputs)
+            (out * probe).mean().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), [p.grad.clone() for p in m.parameters()], [b.clone() for b in m.buffers()]
+
+    base = run(False, False)
+    assert len(Model(ic, num_feature=nf).cuda().side_streams()) == 2
+    for rep in range(3):
+        for direct in (False, True):
+            got = run(True, direct)
+            assert torch.equal(got[0], base[0]), (rep, direct)
+            for i, (a, b) in enumerate(zip(got[1], base[1])):
+                assert torch.equal(a, b), (rep, direct, i)
+            for a, b in zip(got[2], base[2]):
+                assert torch.equal(a, b)
