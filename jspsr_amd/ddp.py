@@ -64,9 +64,10 @@ class GradReducer:
         self._streams = list(streams)
 
     def _join_streams(self):
-        if self.flat.is_cuda and (self._streams or self._home is not None):
+        if self.flat.is_cuda:
+            from . import ops
             cur = torch.cuda.current_stream()
-            for st in self._streams + ([self._home] if self._home is not None else []):
+            for st in self._streams + ops.aux_streams() + ([self._home] if self._home is not None else []):
                 if st != cur:
                     cur.wait_stream(st)
 
@@ -93,7 +94,10 @@ class GradReducer:
             self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Wait for the in-flight bucket reductions and average."""
+        """Wait for the in-flight bucket reductions and average.  Also the point where the calling stream is ordered
+        after the streams gradient kernels were launched on (branch streams, weight-gradient streams): call it after
+        backward() and before the optimizer step, single-GPU runs included."""
+        self._join_streams()
         if self.world == 1:
             return
         for i, left in enumerate(self._pending):  # parameters that received no gradient this step

@@ -5,6 +5,8 @@ current HIP stream to libjspsr_hip.so.  CPU tensors are rejected (no fallback).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -131,6 +133,37 @@ def _wgrad_into(param, G, X, R, C, KH, KW, stride, pad):
             ready(param)
         return None
     return K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad)
+
+
+# ---- weight gradients beside the data-gradient chain -------------------------------------------------------------
+# A conv's weight gradient depends only on (dz, x) and nothing downstream in the backward pass waits for it, while the
+# chain dz -> data gradient -> BatchNorm backward -> ... is what the next layer needs.  The wgrad kernels (MFMA-bound)
+# therefore go to an auxiliary stream per home stream and overlap the memory-bound BatchNorm passes of the chain.
+_aux_streams = {}
+wgrad_async = os.environ.get("JSPSR_WGRAD_ASYNC", "1") != "0"
+
+
+def aux_streams():
+    """Every auxiliary stream created so far (GradReducer orders its collectives / finish() after them)."""
+    return list(_aux_streams.values())
+
+
+def _wgrad_async(param, G, X, R, C, KH, KW, stride, pad):
+    if not wgrad_async:
+        return _wgrad_into(param, G, X, R, C, KH, KW, stride, pad)
+    cur = torch.cuda.current_stream()
+    aux = _aux_streams.get(cur.cuda_stream)
+    if aux is None:
+        aux = _aux_streams[cur.cuda_stream] = torch.cuda.Stream(device=G.device)
+    aux.wait_stream(cur)                     # G and X are complete on the home stream
+    with torch.cuda.stream(aux):
+        dW = _wgrad_into(param, G, X, R, C, KH, KW, stride, pad)
+    G.record_stream(aux)                     # home-pool tensors read by queued aux work
+    X.record_stream(aux)
+    if dW is not None:                       # handed to autograd, which consumes it on the home stream
+        cur.wait_stream(aux)
+        dW.record_stream(cur)
+    return dW
 
 
 def _bn_sink(gparam, bparam):
@@ -277,14 +310,14 @@ class _Conv(torch.autograd.Function):
                     raise RuntimeError("conv backward: gradient w.r.t. a channel-padded input is not supported")
                 dx = K.conv2d_dgrad(dz, K.pack_weight(w, 1, Cg, cdt), (H, W), stride, pad)
             if ctx.needs_input_grad[1]:
-                dW = _wgrad_into(ctx.wparam, dz, x, O, I, KH, KW, stride, pad)
+                dW = _wgrad_async(ctx.wparam, dz, x, O, I, KH, KW, stride, pad)
         else:
             I, O, KH, KW = w.shape
             if ctx.needs_input_grad[0]:
                 # d/dx of a transposed conv = ordinary stride-2 conv of the fine-grid gradient
                 dx = K.conv2d_forward(dz, K.pack_weight(w, 0, Cg, cdt), None, 2, 1, False)
             if ctx.needs_input_grad[1]:
-                dW = _wgrad_into(ctx.wparam, x, dz, I, O, KH, KW, 2, 1)
+                dW = _wgrad_async(ctx.wparam, x, dz, I, O, KH, KW, 2, 1)
         return dx, dW, dbias, None, None, None, None, None, None
 
 
@@ -412,14 +445,14 @@ class _ResUnit(torch.autograd.Function):
         if dres is None:
             dres = dout
         p1, p2, pd = ctx.wparams
-        dW2 = _wgrad_into(p2, dz2, y1, O, O, 3, 3, 1, 1)
+        dW2 = _wgrad_async(p2, dz2, y1, O, O, 3, 3, 1, 1)
         dy1 = K.conv2d_dgrad(dz2, K.pack_weight(w2, 1, O, cdt), y1.shape[1:3], 1, 1)
         del dz2
         dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1, grads_into=sink1)
         if sink1 is not None:
             _bn_ready(pg1, pb1)
         del dy1
-        dW1 = _wgrad_into(p1, dz1, x, O, Cin, 3, 3, stride, 1)
+        dW1 = _wgrad_async(p1, dz1, x, O, Cin, 3, 3, stride, 1)
         dWd = dgd = dbd = None
         side = dres                      # what reaches x along the shortcut
         # gradient of x parked by its other consumer (SliceBuffer.join(defer=...)): rides along as an addend too
@@ -435,7 +468,7 @@ class _ResUnit(torch.autograd.Function):
             dzd, _, dgd, dbd = K.bn_backward(dres, None, zd, gd, md, idd, trd, 0, 1.0, beta=bd, grads_into=sinkd)
             if sinkd is not None:
                 _bn_ready(pgd, pbd)
-            dWd = _wgrad_into(pd, dzd, x, O, Cin, 1, 1, stride, 0)
+            dWd = _wgrad_async(pd, dzd, x, O, Cin, 1, 1, stride, 0)
             side = K.conv2d_dgrad(dzd, K.pack_weight(wd, 1, O, cdt), (H, W), stride, 0, addend=extra) if need_x else None
         dx = None
         if need_x:

@@ -204,8 +204,10 @@ def test_block_level_autograd_node_equals_op_by_op_graph():
 @pytest.mark.parametrize("nf,B,H,W,dtype", [(8, 2, 64, 64, torch.float32), (32, 2, 256, 256, torch.bfloat16)])
 def test_branch_streams_change_nothing(nf, B, H, W, dtype):
     """The guidance branches run on side streams beside the dem branch (forward and, through autograd's stream
-    replay, backward).  Same kernels on the same data in the same per-tensor order: outputs, every parameter
+    replay, backward), and every weight-gradient kernel runs on an auxiliary stream beside the data-gradient chain
+    (ops._wgrad_async).  Same kernels on the same data in the same per-tensor order: outputs, every parameter
     gradient and the BatchNorm buffers must be bit-identical to the single-stream run, on every repetition."""
+    from jspsr_amd import ops
     from jspsr_amd.JSPSR import Model
     from jspsr_amd.ddp import GradReducer
     torch.manual_seed(0)
@@ -222,15 +224,21 @@ def test_branch_streams_change_nothing(nf, B, H, W, dtype):
         m.load_state_dict(state)
         m.compute_dtype = dtype
         m.branch_streams = streams
-        red = GradReducer(m.parameters()) if direct else None
-        for _ in range(2):                       # second step: allocator blocks are being recycled
-            if red is not None:
-                red.zero_grad()
-            else:
-                m.zero_grad(set_to_none=True)
-            out = m(*inputs)
-            (out * probe).mean().backward()
-        torch.cuda.synchronize()
+        keep, ops.wgrad_async = ops.wgrad_async, streams
+        try:
+            red = GradReducer(m.parameters()) if direct else None
+            for _ in range(2):                       # second step: allocator blocks are being recycled
+                if red is not None:
+                    red.zero_grad()
+                else:
+                    m.zero_grad(set_to_none=True)
+                out = m(*inputs)
+                (out * probe).mean().backward()
+                if red is not None:
+                    red.finish()                     # orders this stream after the gradient streams
+            torch.cuda.synchronize()
+        finally:
+            ops.wgrad_async = keep
         return out.detach().clone(), [p.grad.clone() for p in m.parameters()], [b.clone() for b in m.buffers()]
 
     base = run(False, False)
