@@ -173,11 +173,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # rehearsal on a one-GPU box (the real launch is one rank per GPU over RCCL): JSPSR_BENCH_REHEARSAL=1 puts every
+    # rank on cuda:0 and moves the collectives through gloo, so the N > 1 code path can be exercised end to end
+    rehearsal = os.environ.get("JSPSR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
 
     from jspsr_amd import _lib
     from jspsr_amd.JSPSR import Model
