@@ -5,6 +5,7 @@ current HIP stream to libjspsr_hip.so.  CPU tensors are rejected (no fallback).
 """
 from __future__ import annotations
 
+import collections
 import os
 
 import torch
@@ -140,6 +141,8 @@ def _wgrad_into(param, G, X, R, C, KH, KW, stride, pad):
 # chain dz -> data gradient -> BatchNorm backward -> ... is what the next layer needs.  The wgrad kernels (MFMA-bound)
 # therefore go to an auxiliary stream per home stream and overlap the memory-bound BatchNorm passes of the chain.
 _aux_streams = {}
+_marks = {}          # home stream -> events marking recent weight-gradient forks (run-ahead throttle)
+RUN_AHEAD = int(os.environ.get("JSPSR_RUN_AHEAD", "16"))
 wgrad_async = os.environ.get("JSPSR_WGRAD_ASYNC", "1") != "0"
 
 
@@ -160,6 +163,16 @@ def _wgrad_async(param, G, X, R, C, KH, KW, stride, pad):
         dW = _wgrad_into(param, G, X, R, C, KH, KW, stride, pad)
     G.record_stream(aux)                     # home-pool tensors read by queued aux work
     X.record_stream(aux)
+    # Run-ahead throttle.  A block released while another stream still has work queued is handed out again only after
+    # that stream has drained everything queued up to the release; the host enqueues a whole backward pass in a
+    # fraction of the time the GPU needs for it, so without a bound almost nothing freed during a backward pass is
+    # reusable within it (measured: 160 GiB reserved for a 24 GiB working set).  The host therefore never gets more
+    # than RUN_AHEAD weight-gradient launches (about five residual blocks) ahead of the GPU -- still far more queued
+    # work than the launch latency needs.
+    marks = _marks.setdefault(cur.cuda_stream, collections.deque())
+    marks.append(cur.record_event())
+    if len(marks) > RUN_AHEAD:
+        marks.popleft().synchronize()
     if dW is not None:                       # handed to autograd, which consumes it on the home stream
         cur.wait_stream(aux)
         dW.record_stream(cur)
