@@ -42,9 +42,14 @@ class Generator(nn.Module):
     def heads(self, feature):
         """NHWC weight (B,H,W,9) after the sigmoid and the 16 learned offset channels (B,H,W,16)."""
         cw, co = self.conv_weight[0], self.conv_offset.conv[0]
-        weight = E.sigmoid(E.conv2d(feature, cw.weight, cw.bias))
-        off16 = E.conv2d(feature, co.weight, co.bias)
-        return weight, off16
+        # the two 1x1 heads (spn.py:66-68) read the same full-resolution feature: one conv with 9 + 16 (+ 7 zero)
+        # output channels reads it once, and its backward is one data-gradient launch instead of two plus an add
+        nw, no = cw.weight.shape[0], co.weight.shape[0]
+        pad = (-(nw + no)) % 8
+        w_all = torch.cat((cw.weight, co.weight, cw.weight.new_zeros((pad,) + tuple(cw.weight.shape[1:]))), 0)
+        b_all = torch.cat((cw.bias, co.bias, cw.bias.new_zeros(pad)))
+        y = E.conv2d(feature, w_all, b_all)
+        return E.sigmoid(y[..., :nw]), y[..., nw:nw + no]
 
     def forward(self, dem, context):
         """Reference contract: NCHW in, (weight (B,9,H,W), offset (B,18,H,W)) NCHW fp32 out."""
