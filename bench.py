@@ -126,6 +126,41 @@ def time_k1(model, inputs, iters=20):
     }
 
 
+def time_convs(batch, dtype, iters=10):
+    """MFMA utilisation of the conv kernels (north_star asks for it beside K1's HBM fraction): the 3x3 / stride-1
+    layer shapes of the benchmarked model, each pass (forward, data gradient, weight gradient) launched `iters`
+    times back to back through the C ABI between two events on the launch stream; algorithmic flops = 2*M*N*K."""
+    from jspsr_amd import kernels as K
+    peak = 2500.0 if dtype == torch.bfloat16 else 157.0       # dense TFLOP/s, MI355X_MICROARCH.md
+    shapes = [(TILE, 64, 64), (TILE, 128, 128), (TILE // 2, 128, 128), (TILE // 4, 256, 256), (TILE // 8, 512, 512)]
+    rows, tot_f, tot_t = [], 0.0, 0.0
+    for hw, ci, co in shapes:
+        x = torch.randn(batch, hw, hw, ci, device="cuda").to(dtype)
+        go = torch.randn(batch, hw, hw, co, device="cuda").to(dtype)
+        w = torch.randn(co, ci, 3, 3, device="cuda") / (ci * 9) ** 0.5
+        wp, wpt = K.pack_weight(w, 0, ci, dtype), K.pack_weight(w, 1, co, dtype)
+        flops = 2.0 * batch * hw * hw * co * ci * 9
+        fns = {"fwd": lambda: K.conv2d_forward(x, wp, None, 1, 1), "dgrad": lambda: K.conv2d_dgrad(go, wpt, (hw, hw), 1, 1),
+               "wgrad": lambda: K.conv2d_wgrad(go, x, co, ci, 3, 3, 1, 1)}
+        for name, fn in fns.items():
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1) / iters * 1e-3
+            rows.append({"layer": f"{batch}x{hw}x{hw} {ci}->{co} 3x3 {name}", "tflops": round(flops / t / 1e12, 1)})
+            tot_f += flops
+            tot_t += t
+    ach = tot_f / tot_t / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "note": "flop-weighted over the rows; wgrad rows include the ordered slab reduction launch", "rows": rows}
+
+
 def cpu_baseline():
     """Oracle (CPU restatement, fp32, torch CPU kernels) on one 512x512 tile: fwd + loss + bwd."""
     from oracle import jspsr_ref as R
@@ -235,6 +270,7 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = time_k1(model, inputs)
+        roof["convs"] = time_convs(args.batch, model.compute_dtype)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
