@@ -496,7 +496,10 @@ PatchPlan make_patch_plan(int B, int H, int W, int Cg, int Cx) {
   if (W % U || Cg < 32 || Cx < 32) return p;
   const long long pairs = (long long)((Cg + 63) / 64) * ((Cx + 63) / 64);
   const long long strips = (long long)B * (W / U);
-  static const int target = [] { const char* e = getenv("JSPSR_WGRAD_UNITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();   // 2 resident workgroups x 256 CUs (swept 256..1024 on MI355X)
+  // one workgroup per CU: alone on the chip 512 (two per CU) measured 5-10 % faster, but in the training step the kernel
+  // runs on an auxiliary stream beside the data-gradient chain, and with 75 KB of LDS per workgroup a second one would
+  // take the slot a conv workgroup (64.5 KB) can otherwise share the CU through (step: 64.8 -> 64.1 ms)
+  static const int target = [] { const char* e = getenv("JSPSR_WGRAD_UNITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
   long long want = (target + pairs * strips - 1) / (pairs * strips);   // row blocks per strip
   if (want < 1) want = 1;
   int rows = (int)((H + want - 1) / want);
