@@ -328,3 +328,37 @@ def test_conv_epilogue_statistics(dtype, B, H, W, Cin, Cout, k, stride, pad):
     s = st.double().sum(0).cpu()
     assert _relerr(s[0], ref.sum((0, 2, 3))) < 1e-4
     assert _relerr(s[1], (ref * ref).sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("env", [{"JSPSR_CONV_TALL": "2"}, {"JSPSR_CONV_NOPATCH": "1"}, {"JSPSR_WGRAD_NOPATCH": "1"},
+                                 {"JSPSR_CONV_TALL": "0"}])
+def test_opt_in_kernel_variants_in_a_child_process(env):
+    """The library reads its lab switches once per process: the opt-in / fallback instantiations (8-wave 256x128 tile,
+    generic implicit-GEMM kernel only, generic weight-gradient kernel only, no 16x16 tile) are exercised in a child
+    process against the same fp64 reference, so that they stay correct while they are not the default."""
+    import subprocess
+    import sys
+    code = r"""
+import torch, torch.nn.functional as F
+from jspsr_amd import kernels as K
+g = torch.Generator().manual_seed(0)
+for (B, H, W, Ci, Co) in [(2, 256, 256, 64, 128), (4, 256, 256, 64, 64)]:
+    x = torch.randn(B, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).bfloat16().float()
+    go = torch.randn(B, Co, H, W, generator=g).bfloat16().float()
+    xr = x.double().requires_grad_(); wr = w.double().requires_grad_()
+    y = F.conv2d(xr, wr, None, 1, 1); y.backward(go.double())
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+    rel = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
+    yd = K.conv2d_forward(nh(x), K.pack_weight(w.cuda(), 0, Ci, torch.bfloat16), None, 1, 1)
+    dx = K.conv2d_dgrad(nh(go), K.pack_weight(w.cuda(), 1, Co, torch.bfloat16), (H, W), 1, 1)
+    dw = K.conv2d_wgrad(nh(go), nh(x), Co, Ci, 3, 3, 1, 1)
+    assert rel(yd.float().permute(0, 3, 1, 2), y.detach()) < 6e-3
+    assert rel(dx.float().permute(0, 3, 1, 2), xr.grad) < 6e-3
+    assert rel(dw, wr.grad) < 1e-5
+print("variants ok")
+"""
+    import os
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "variants ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
