@@ -116,11 +116,13 @@ int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const flo
  * wpack_t: mode-1 packing with c_pad = Cg.  One launch per stride phase (no wasted taps).
  * addend (may be NULL): a tensor on gin's grid, Cin channels at pitch add_cstride, added in the epilogue --
  * gin = [relu](...) + addend.  It carries the gradient that reaches the same tensor along another path (the
- * residual branch of a BasicBlock, basics.py:113-122), which autograd would otherwise add in a separate pass. */
+ * residual branch of a BasicBlock, basics.py:113-122), which autograd would otherwise add in a separate pass.
+ * scale (may be NULL): per-channel factor as in jspsr_conv2d_forward -- ConvTranspose2d -> BatchNorm(eval) -> ReLU
+ * of the decoder (basics.py:69-85) in one launch at inference.  gin = [relu](acc * scale + bias + addend). */
 int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,
                        int B, int OH, int OW, int Cg, int g_cstride, int g_coff, int IH, int IW,
                        int Cin, int in_cstride, int in_coff, int KH, int KW, int stride, int pad,
-                       int relu, const void* addend, int add_cstride, jspsr_stream_t stream);
+                       int relu, const void* addend, int add_cstride, const float* scale, jspsr_stream_t stream);
 
 /* Weight gradient (autograd of nn.Conv2d / nn.ConvTranspose2d w.r.t. .weight):
  *   dW[r][c][ky][kx] = sum_{b,oy,ox} G[b,oy,ox,r] * X[b, oy*stride-pad+ky, ox*stride-pad+kx, c]

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("JSPSR_LAB_LIB") or os.path.join(_HERE, "lib", "libjspsr_hip.so")  # JSPSR_LAB_LIB: kernel-lab builds only
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lock = threading.Lock()
 _lib = None
@@ -34,7 +34,7 @@ SIGNATURES = {
     "jspsr_conv2d_stats_rows": (c_i, [c_i, c_i, c_i]),
     "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p, c_p, c_p, c_i, c_p]),
     "jspsr_bn_fold": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p]),
-    "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p, c_i, c_p]),
+    "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p, c_i, c_p, c_p]),
     "jspsr_conv2d_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i] * 8),
     "jspsr_conv2d_wgrad": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p, c_p]),
     "jspsr_reduce_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),

@@ -8,9 +8,11 @@ Key patterns reproduced: ``<unit>.conv.0.{weight,bias}``, ``<unit>.conv.bn.*``,
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from . import engine as E
+from . import ops
 
 
 class ChannelGate(nn.Module):
@@ -61,8 +63,11 @@ class UpUnit(nn.Module):
 
     def forward(self, x, dest=None):
         y = self.dconv[0](x)
+        bn = self.dconv.bn
+        if not torch.is_grad_enabled() and not (bn.training or bn.running_mean is None):   # inference: one launch per phase
+            return ops.conv_transpose_bn_infer(y, self.dconv[1].weight, bn.weight, bn.bias, E._bn_state(bn), True, dest)
         y = E.conv_transpose2d(y, self.dconv[1].weight)
-        return E.batch_norm(y, self.dconv.bn, relu=True, dest=dest)
+        return E.batch_norm(y, bn, relu=True, dest=dest)
 
 
 class ResUnit(nn.Module):

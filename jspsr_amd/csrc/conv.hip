@@ -916,7 +916,8 @@ extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack
 extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,
                                   int B, int OH, int OW, int Cg, int g_cstride, int g_coff, int IH, int IW,
                                   int Cin, int in_cstride, int in_coff, int KH, int KW, int stride, int pad,
-                                  int relu, const void* addend, int add_cstride, jspsr_stream_t stream) {
+                                  int relu, const void* addend, int add_cstride, const float* scale,
+                                  jspsr_stream_t stream) {
   if (int e = check_common(dtype, gout, wpack_t, gin, Cg, g_cstride, g_coff, in_cstride, in_coff, Cin, "conv2d_dgrad")) return e;
   if (addend && add_cstride < Cin) return fail(JSPSR_EINVAL, "conv2d_dgrad: addend pitch %d < %d channels", add_cstride, Cin);
   if (B <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
@@ -940,7 +941,7 @@ extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack
       g.iy_mul = 1; g.iy_add = (py + pad - g.ky0) / stride; g.ix_mul = 1; g.ix_add = (px + pad - g.kx0) / stride;
       g.sign = -1; g.KH = KH; g.KW = KW;
       g.oy_mul = stride; g.oy_add = py; g.ox_mul = stride; g.ox_add = px; g.relu = relu;
-      g.addend = addend; g.add_cstride = add_cstride;
+      g.addend = addend; g.add_cstride = add_cstride; g.scale = scale;
       const int e = dtype == JSPSR_F32 ? launch<float>(gout, wpack_t, bias, gin, nullptr, g, s)
                                        : launch<__bf16>(gout, wpack_t, bias, gin, nullptr, g, s);
       if (e) return e;

@@ -112,7 +112,8 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
     return (out, st) if stats else out
 
 
-def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0, addend=None):
+def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0, addend=None,
+                 scale=None):
     """g (B,OH,OW,Cgs) NHWC, wpack_t [Cin][KH][KW][Cg] -> (B,IH,IW,Cin): data gradient of a conv /
     forward of a transposed conv.  addend (B,IH,IW,Cin): added in the epilogue (a gradient arriving along
     another path)."""
@@ -133,7 +134,8 @@ def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None
                                       B, OH, OW, Cg, Cgs, g_coff, IH, IW, Cin, pitch(out), out_coff,
                                       KH, KW, stride, pad, int(relu),
                                       addend.data_ptr() if addend is not None else None,
-                                      pitch(addend) if addend is not None else 0, _stream()), "jspsr_conv2d_dgrad")
+                                      pitch(addend) if addend is not None else 0,
+                                      scale.data_ptr() if scale is not None else None, _stream()), "jspsr_conv2d_dgrad")
     return out
 
 

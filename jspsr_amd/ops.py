@@ -507,6 +507,23 @@ def conv_bn_infer(x, weight, gamma, beta, bn, stride, pad, relu=False, res=None,
                             scale=sc, addend=K.nhwc(res) if res is not None else None)
 
 
+def conv_transpose_bn_infer(x, weight, gamma, beta, bn, relu=True, dest=None):
+    """Inference: ConvTranspose2d(k3 s2 p1 op1) -> BatchNorm(eval) (-> ReLU) of the decoder (basics.py:69-85), one
+    launch per stride phase with the normalisation folded into the epilogue."""
+    x = K.nhwc(x)
+    rm, rv, _, eps, training = bn
+    if training or rm is None:
+        raise RuntimeError("conv_transpose_bn_infer: BatchNorm must be in eval mode with running statistics")
+    I, O, KH, KW = weight.shape
+    B, H, W, Cp = x.shape
+    if Cp != I or KH != 3:
+        raise ValueError("conv_transpose: only k3 s2 p1 op1 without channel padding is built")
+    sc, sh = K.bn_fold(gamma.detach(), beta.detach(), rm, rv, eps, 1.0)
+    out = dest[0].slice(dest[1], O, (B, 2 * H, 2 * W)) if dest is not None else None
+    return K.conv2d_dgrad(x, K.pack_weight(weight.detach().contiguous(), 1, Cp, x.dtype), (2 * H, 2 * W), 2, 1, bias=sh,
+                          relu=relu, out=out, scale=sc)
+
+
 def res_unit_infer(x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, scale, act, bns, dest=None):
     """BasicBlock in inference mode: three (two without projection) launches, nothing else touches the tensors."""
     y1 = conv_bn_infer(x, w1, g1, b1, bns[0], stride, 1, relu=True)
