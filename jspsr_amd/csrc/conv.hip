@@ -572,13 +572,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WGN, wn = wave % WGN;
   const int lr = lane & 31, lh = lane >> 5;
-  // A operand: MFMA row lr of block mi is tile pixel (dy, dx) = ((wm*WTM + mi*32 + lr) / 16, lr % 16);
-  // at tap (ty,tx) it reads patch pixel (dy + oy(ty), dx + ox(tx))
+  // A operand: MFMA row R of the tile is tile pixel (dy, dx) = (R / 16, (R + rot * dy) % 16); at tap (ty,tx) it reads
+  // patch pixel (dy + oy(ty), dx + ox(tx)).  The rotation by `rot` per tile row undoes the skew of the patch pitch: a
+  // 32-row MFMA block spans two tile rows PW = 16 + ntx - 1 patch pixels apart, and with 144-byte pixel rows two
+  // lanes of one ds_read_b128 lane group share a bank exactly when their patch pixel indices agree mod 16 -- with
+  // dx = R % 16 the second row's indices are shifted by PW - 16 against the first's and 2 of 16 lanes collide
+  // (measured: 23 % of the kernel's LDS cycles were bank conflicts); rotated, every group covers 16 distinct residues.
+  const int rot = (16 - ((PW - TLW) & (TLW - 1))) & (TLW - 1);
   int a_ld[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int row = wm * WTM + mi * 32 + lr;
-    a_ld[mi] = ((row >> 4) * PW + (row & (TLW - 1))) * ROWB + lh * 16;
+    a_ld[mi] = ((row >> 4) * PW + ((row + rot * (row >> 4)) & (TLW - 1))) * ROWB + lh * 16;
   }
   const char* const b_ld = Bs + (wn * WTN + lr) * ROWB + lh * 16;
 
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
 
   // ---- epilogue (as above): transpose through LDS, 16-byte stores ----------------------------
   auto out_pixel = [&](int row) -> long long {
-    const int y = ty0 + (row >> 4), x = tx0 + (row & (TLW - 1));
+    const int y = ty0 + (row >> 4), x = tx0 + ((row + rot * (row >> 4)) & (TLW - 1));
     const int oy = y * g.oy_mul + g.oy_add, ox = x * g.ox_mul + g.ox_add;
     return (y < g.MH && x < g.MW && oy < g.OH && ox < g.OW) ? ((long long)bimg * g.OH + oy) * g.OW + ox : -1;
   };
