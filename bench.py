@@ -303,6 +303,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()            # rank 0 ran its micro-benchmarks and printed; leave together
         dist.destroy_process_group()
 
 
