@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
+from .blocks import HotPathModule
 from .spn import Generator, PostProcessor
 
 
@@ -31,7 +32,7 @@ class ResBlock(nn.Module):
         return r * self.res_scale + x
 
 
-class EDSR(nn.Module):
+class EDSR(HotPathModule):
     def __init__(self, in_channels=3, out_channels=3, n_resblocks=16, n_features=64, scale=2, res_scale=0.1,
                  spn=False):
         super().__init__()

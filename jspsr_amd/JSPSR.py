@@ -15,13 +15,13 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
-from .blocks import ConvUnit, ResUnit, UpUnit
+from .blocks import ConvUnit, HotPathModule, ResUnit, UpUnit
 from .spn import Generator, PostProcessor
 
 _AUX_KEYS = ("mask", "canopy", "coord")
 
 
-class Model(nn.Module):
+class Model(HotPathModule):
     def __init__(self, in_channels: dict, out_channels: int = 1, num_feature: int = 32,
                  layers: tuple = (2, 2, 2, 2), res_scale: tuple = (1, 1, 1, 1), spn: bool = True,
                  spn_scale: int = 1):
@@ -218,5 +218,7 @@ class Model(nn.Module):
         c0 = self.conv0(x)
         dem = dem.detach()  # :372
         weight, off16 = self.generator.heads(self.generator.features(dem_a.detach(), c0))
+        if E._offset_probe is not None:
+            E._offset_probe.append(off16)
         # K1 reads planar fp32 operands; 16-channel offsets: the zero centre pair is implicit
         return self.postprocessor(dem.float(), E.to_nchw_f32(weight), E.to_nchw_f32(off16))

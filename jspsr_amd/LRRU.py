@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
-from .blocks import ConvUnit, ResUnit
+from .blocks import ConvUnit, HotPathModule, ResUnit
 from .JSPSR import Model as _JSPSR
 
 
@@ -78,7 +78,7 @@ class PostProcess(nn.Module):
         return E.propagate(depth, weight, offset, self.w, self.b, 1.0)
 
 
-class Model(nn.Module):
+class Model(HotPathModule):
     def __init__(self, args, layers=(2, 2, 2, 2, 2)):
         super().__init__()
         self.args = args

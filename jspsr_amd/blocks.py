@@ -15,6 +15,20 @@ from . import engine as E
 from . import ops
 
 
+class HotPathModule(nn.Module):
+    """Base of the drop-in model classes.  The reference's loop clears gradients with
+    ``model.zero_grad(set_to_none=True)`` (train/train_utils.py:210); when a ``GradReducer`` has been attached
+    (``reducer.attach(model)``) the gradients alias its flat communication buffer, so clearing them means zeroing that
+    buffer and keeping the aliases."""
+
+    def zero_grad(self, set_to_none: bool = True):
+        red = self.__dict__.get("_grad_reducer")
+        if red is not None:
+            red.zero_grad()
+        else:
+            super().zero_grad(set_to_none)
+
+
 class ChannelGate(nn.Module):
     """Holds the shared bias-free 1x1 MLP of ChannelAttention (resnet_cbam.py:36-53)."""
 

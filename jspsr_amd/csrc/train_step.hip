@@ -209,8 +209,10 @@ extern "C" int jspsr_adamw_step(float* param, const float* grad, float* exp_avg,
     return fail(JSPSR_EALIGN, "adamw_step: buffers must be 4-byte aligned and equally offset from a 16-byte boundary");
   int head = (int)(((16 - mis) & 15) >> 2);
   if (head > n) head = (int)n;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  // bias corrections in double on the host, as torch.optim.AdamW computes them (float powf is ~3e-5 relative off at
+  // small step counts)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   long long b = (n / 4 + 255) / 256;
   const int blocks = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg,

@@ -32,8 +32,10 @@ class GradReducer:
         start = off = 0
         count = 0
         per = max(1, bucket_bytes // self.flat.element_size())
+        offsets = {}
         for p in reversed(self.params):
             n = p.numel()
+            offsets[id(p)] = off
             p.grad = self.flat[off:off + n].view_as(p)
             self._bucket_of[p] = len(self.buckets)
             off += n
@@ -43,8 +45,11 @@ class GradReducer:
                 start, count = off, 0
         if count:
             self.buckets.append((start, off, count))
-        self._pending = [0] * len(self.buckets)
+        self._offsets = [offsets[id(p)] for p in self.params]
+        self._pending = [b[2] for b in self.buckets]    # a backward before the first zero_grad() counts correctly too
+        self._reduced = [0] * len(self.buckets)
         self._seen = set()
+        self._direct = set()
         self._works = []
         self._streams, self._home = [], None
         if self.world > 1:
@@ -56,7 +61,28 @@ class GradReducer:
         # gradients to autograd
         for p in self.params:
             p._jspsr_direct_grad = True
-            p._jspsr_grad_ready = self._hook if self.world > 1 else None
+            p._jspsr_grad_ready = self._direct_ready
+
+    def attach(self, module: torch.nn.Module):
+        """Let `module.zero_grad(...)` -- what the reference's loop calls every iteration with set_to_none=True
+        (train/train_utils.py:210) -- zero this reducer's flat buffer and keep the gradient aliases, instead of
+        dropping them (jspsr_amd.JSPSR.Model / LRRU.Model / EDSR honour `_grad_reducer`)."""
+        module.__dict__["_grad_reducer"] = self
+        return self
+
+    def _direct_ready(self, p):
+        """Readiness report of a kernel that added its gradient straight into the flat buffer.  It is issued when the
+        FIRST contribution is enqueued; a layer applied twice in one forward would have its bucket reduced before the
+        second contribution lands, so a second direct report for the same parameter in one step is an error."""
+        if id(p) in self._direct:
+            if self.world > 1:
+                raise RuntimeError("GradReducer: a layer with in-place weight gradients was applied more than once in one "
+                                   "forward; shared layers are not supported by the direct-gradient path under data "
+                                   "parallelism")
+            return
+        self._direct.add(id(p))
+        if self.world > 1:
+            self._hook(p)
 
     def watch_streams(self, streams):
         """Side streams whose backward kernels write gradients into the flat buffer (Model.side_streams()): a
@@ -75,9 +101,27 @@ class GradReducer:
         """Gradients alias the flat buffer: zero it in one kernel, keep the aliases."""
         self._home = torch.cuda.current_stream() if self.flat.is_cuda else None
         self.flat.zero_()
+        base, es = self.flat.data_ptr(), self.flat.element_size()
+        for p, off in zip(self.params, self._offsets):   # aliases dropped or replaced (zero_grad(set_to_none=True)): restore
+            g = p.grad
+            if g is None or g.data_ptr() != base + off * es:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
         self._pending = [b[2] for b in self.buckets]
+        self._reduced = [0] * len(self.buckets)
         self._seen = set()
+        self._direct = set()
         self._works = []
+
+    def _check_aliases(self):
+        base, es = self.flat.data_ptr(), self.flat.element_size()
+        for p, off in zip(self.params, self._offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != base + off * es or g.shape != p.shape:
+                raise RuntimeError(
+                    "GradReducer: a parameter's .grad no longer aliases the flat gradient buffer (was "
+                    "model.zero_grad(set_to_none=True) or optimizer.zero_grad() of another optimizer called after "
+                    "reducer.zero_grad()?).  Use reducer.zero_grad() / FlatAdamW.zero_grad(), or reducer.attach(model) "
+                    "so that model.zero_grad() does the right thing.")
 
     def _hook(self, p):
         # A parameter reports once per step.  Kernels that write a gradient straight into the flat buffer report by
@@ -91,6 +135,7 @@ class GradReducer:
         if self._pending[i] == 0:
             s, e, _ = self.buckets[i]
             self._join_streams()
+            self._reduced[i] += 1
             self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -98,17 +143,24 @@ class GradReducer:
         after the streams gradient kernels were launched on (branch streams, weight-gradient streams): call it after
         backward() and before the optimizer step, single-GPU runs included."""
         self._join_streams()
+        self._check_aliases()
         if self.world == 1:
             return
         for i, left in enumerate(self._pending):  # parameters that received no gradient this step
             if left > 0:
                 s, e, _ = self.buckets[i]
+                self._reduced[i] += 1
                 self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 self._pending[i] = 0
+        if any(left < 0 for left in self._pending) or any(n != 1 for n in self._reduced):
+            raise RuntimeError(f"GradReducer: bucket bookkeeping broken (pending {self._pending}, reductions per bucket "
+                               f"{self._reduced}): every bucket must be reduced exactly once per step -- call "
+                               "reducer.zero_grad() before every backward pass")
         for w in self._works:
             w.wait()
         self._works = []
         self.flat.div_(self.world)
+        self._reduced = [0] * len(self.buckets)      # a second finish() without a new step is an error too
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):

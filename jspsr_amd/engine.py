@@ -15,6 +15,7 @@ from . import ops
 
 _compute_dtype = torch.float32
 _gate_sync = None   # set by jspsr_amd.tiling during sharded inference (scene-wide gate statistics)
+_offset_probe = None   # a list during sharded inference: the models append their learned-offset tensors (halo check)
 
 
 class compute_dtype:

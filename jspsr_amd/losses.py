@@ -52,7 +52,17 @@ class MultiLoss(torch.nn.Module):
     def __init__(self, l1=1.0, l2=1.0, grad=0.1):
         super().__init__()
         self.weights = (float(l1), float(l2), float(grad))
+        self.out = {}
 
     def forward(self, pred, gt):
         v = _FusedLoss.apply(pred, gt, *self.weights)
-        return {"L1": v[0].detach(), "L2": v[1].detach(), "Grad": v[2].detach(), "Total": v[3]}
+        self.out = {"L1": v[0].detach(), "L2": v[1].detach(), "Grad": v[2].detach(), "Total": v[3]}
+        return self.out
+
+    def reset(self):
+        """The reference's train loop calls criterion.reset() every iteration (train/train_utils.py:206;
+        loss_schemes.py:74-75)."""
+        self.out = {}
+
+    def __str__(self):
+        return f"{self.__class__.__name__}:: ['L1', 'L2', 'Grad'], {list(self.weights)}, fused HIP (jspsr_loss_forward/backward)"

@@ -72,8 +72,35 @@ class FlatAdamW:
                                                 hi - lo, g["lr"], self.betas[0], self.betas[1], self.eps,
                                                 self.weight_decay, self.steps, stream), "jspsr_adamw_step")
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()
+
+    # -- checkpointing: the reference saves optimizer.state_dict() with every best model (main.py:246-252) and
+    #    restores it on resume (utils/utils.py:394) -------------------------------------------------------------------
+    def state_dict(self):
+        """Flat moments + step count + per-group learning rates; tensors are clones (safe to torch.save)."""
+        return {
+            "state": {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
+                      "step": int(self.steps)},
+            "param_groups": [{"lr": g["lr"], "initial_lr": g["initial_lr"], "ranges": [list(r) for r in g["ranges"]],
+                              "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay}
+                             for g in self.param_groups],
+            "numel": int(self.flat_p.numel()),
+        }
+
+    def load_state_dict(self, sd):
+        """In place: the parameters keep aliasing `flat_p`, the gradients keep aliasing the reducer's buffer."""
+        if int(sd["numel"]) != self.flat_p.numel() or len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("FlatAdamW.load_state_dict: checkpoint was written for a different parameter layout")
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            if [list(r) for r in sg["ranges"]] != [list(r) for r in g["ranges"]]:
+                raise ValueError("FlatAdamW.load_state_dict: parameter-group ranges differ")
+            g["lr"], g["initial_lr"] = float(sg["lr"]), float(sg["initial_lr"])
+        first = sd["param_groups"][0]
+        self.betas, self.eps, self.weight_decay = tuple(first["betas"]), float(first["eps"]), float(first["weight_decay"])
+        self.exp_avg.copy_(sd["state"]["exp_avg"])
+        self.exp_avg_sq.copy_(sd["state"]["exp_avg_sq"])
+        self.steps = int(sd["state"]["step"])
 
 
 class WarmupStepLR:

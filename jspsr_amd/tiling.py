@@ -34,6 +34,13 @@ class Strip:
     y1: int
     ty0: int     # window rows [ty0, ty1) actually fed to the model (interior + halo, clamped)
     ty1: int
+    H: int = 0   # scene height (0: unknown)
+
+    def margins(self):
+        """Rows of real neighbour data above / below the interior; an edge on the scene border needs none (the window's
+        zero padding there IS the scene's)."""
+        big = 1 << 30
+        return (self.y0 - self.ty0 if self.ty0 > 0 else big), (self.ty1 - self.y1 if (self.H == 0 or self.ty1 < self.H) else big)
 
 
 def plan_strips(H: int, world: int, halo: int = 128) -> List[Strip]:
@@ -46,7 +53,7 @@ def plan_strips(H: int, world: int, halo: int = 128) -> List[Strip]:
     for r in range(world):
         y0, y1 = min(H, r * rows), min(H, (r + 1) * rows)
         ty0 = max(0, min(y0 - halo, H - win))
-        out.append(Strip(y0, y1, ty0, ty0 + win))
+        out.append(Strip(y0, y1, ty0, ty0 + win, H))
     return out
 
 
@@ -77,8 +84,17 @@ class _GateSync:
         return self.combine(torch.cat(sums), cnt, torch.cat(maxs))
 
 
+RECEPTIVE_RADIUS = 97   # stem 2 + encoder 4+8+16+32 + decoder 16+8+4 + conv0 1 + generator 5 + 3x3 sampler 1
+
+
+class HaloTooSmall(RuntimeError):
+    pass
+
+
 def _combine_ranks(group=None):
     def f(s, cnt, mx):
+        if s.shape[0] != 1:
+            raise ValueError("cross-rank gate statistics are defined for one scene per call (batch size 1)")
         buf = torch.cat((s.flatten(), cnt))
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
@@ -93,29 +109,70 @@ def _combine_batch(s, cnt, mx):
     return (s.sum(0, keepdim=True) / cnt.sum()).expand(B, -1).contiguous(), mx.amax(0, keepdim=True).expand(B, -1).contiguous()
 
 
-def _run(model, tiles, windows, combine):
+def _run(model, tiles, windows, combine, check_reach=True):
+    """-> (output, reach); reach[b] = max |learned offset| in pixels over the interior rows of window b.
+    check_reach: raise HaloTooSmall unless reach + RECEPTIVE_RADIUS fits into the rows of real neighbour data the window
+    holds beyond every interior edge -- the condition under which a strip equals the monolithic forward (SURVEY.md 8e:
+    the offsets are unbounded reals, so exactness is checked per scene, not assumed)."""
     if model.training:
         raise RuntimeError("sharded inference needs model.eval(): BatchNorm batch statistics would couple the strips")
-    prev = E._gate_sync
+    prev, prev_probe = E._gate_sync, E._offset_probe
     E._gate_sync = _GateSync(windows, combine)
+    E._offset_probe = probe = []
     try:
         with torch.no_grad():
-            return model(*tiles)
+            out = model(*tiles)
     finally:
-        E._gate_sync = prev
+        E._gate_sync, E._offset_probe = prev, prev_probe
+    reach = []
+    for b, s in enumerate(windows):
+        r = 0.0
+        for off in probe:                                   # NHWC (B,h,w,16) learned offsets of a propagation step
+            rows = off[b, s.y0 - s.ty0:s.y1 - s.ty0]
+            if rows.numel():
+                r = max(r, rows.abs().max().item())
+        reach.append(r)
+        margin = min(s.margins())
+        if check_reach and r + RECEPTIVE_RADIUS > margin:
+            raise HaloTooSmall(f"strip rows [{s.y0},{s.y1}): learned offsets reach {r:.1f} px; with the receptive radius of "
+                               f"{RECEPTIVE_RADIUS} px that needs {r + RECEPTIVE_RADIUS:.0f} halo rows, the window holds {margin}")
+    return out, reach
 
 
-def sharded_forward(model, inputs: Sequence[torch.Tensor], rank: int, world: int, halo: int = 128, group=None):
+def sharded_forward(model, inputs: Sequence[torch.Tensor], rank: int, world: int, halo: int = 128, group=None,
+                    check_reach=True, return_reach=False):
     """This rank's interior rows of model(*inputs) for a scene every rank can address
     (`inputs`: full-scene (B=1,C,H,W) tensors, e.g. memory-mapped; only the window is touched)."""
+    if inputs[0].shape[0] != 1:
+        raise ValueError("sharded_forward: one scene per call (batch size 1)")
     H = inputs[0].shape[2]
     s = plan_strips(H, world, halo)[rank]
     tiles = [t[:, :, s.ty0:s.ty1].contiguous().cuda() for t in inputs]
-    out = _run(model, tiles, [s], _combine_ranks(group))
-    return out[:, :, s.y0 - s.ty0:s.y1 - s.ty0]
+    out, reach = _run(model, tiles, [s], _combine_ranks(group), check_reach)
+    out = out[:, :, s.y0 - s.ty0:s.y1 - s.ty0]
+    return (out, reach[0]) if return_reach else out
 
 
-def emulate_sharded_forward(model, inputs: Sequence[torch.Tensor], world: int, halo: int = 128):
+def sharded_forward_owned(model, own: Sequence[torch.Tensor], scene_h: int, halo: int = 128, group=None,
+                          check_reach=True, return_reach=False):
+    """Config 5 as SURVEY.md 8e states it: every rank HOLDS ONLY ITS STRIP.  `own`: this rank's rows
+    [y0, y1) of each input, (1,C,y1-y0,W) on the GPU.  The window plan is `plan_strips` (the same one the
+    single-process emulation and `sharded_forward` use); the window's missing rows come from the neighbouring ranks
+    by point-to-point send/recv (`exchange_window`), once per scene; the channel-gate statistics are all-reduced
+    (SUM, MAX) at the four gated layers.  Returns this rank's interior rows of the scene's prediction."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    strips = plan_strips(scene_h, world, halo)
+    s = strips[rank]
+    if any(t.shape[0] != 1 or t.shape[2] != s.y1 - s.y0 for t in own):
+        raise ValueError(f"sharded_forward_owned: rank {rank} owns rows [{s.y0},{s.y1}) -- got {[tuple(t.shape) for t in own]}")
+    tiles = [exchange_window(t.cuda(), strips, group) for t in own]
+    out, reach = _run(model, tiles, [s], _combine_ranks(group), check_reach)
+    out = out[:, :, s.y0 - s.ty0:s.y1 - s.ty0]
+    return (out, reach[0]) if return_reach else out
+
+
+def emulate_sharded_forward(model, inputs: Sequence[torch.Tensor], world: int, halo: int = 128, check_reach=True,
+                            return_reach=False):
     """Same algorithm in ONE process: the strips are stacked along the batch axis and the
     cross-rank reductions become reductions over that axis.  Used to prove exactness against the
     monolithic forward on a single GPU (tests/test_tiling_gpu.py)."""
@@ -123,26 +180,55 @@ def emulate_sharded_forward(model, inputs: Sequence[torch.Tensor], world: int, h
     H = inputs[0].shape[2]
     strips = plan_strips(H, world, halo)
     tiles = [torch.cat([t[:, :, s.ty0:s.ty1] for s in strips]).contiguous() for t in inputs]
-    out = _run(model, tiles, strips, _combine_batch)
-    return torch.cat([out[i:i + 1, :, s.y0 - s.ty0:s.y1 - s.ty0] for i, s in enumerate(strips)], 2)
+    out, reach = _run(model, tiles, strips, _combine_batch, check_reach)
+    out = torch.cat([out[i:i + 1, :, s.y0 - s.ty0:s.y1 - s.ty0] for i, s in enumerate(strips)], 2)
+    return (out, reach) if return_reach else out
 
 
-def exchange_halo(strip: torch.Tensor, halo: int, group=None) -> torch.Tensor:
-    """Each rank holds only its own rows (B,C,rows,W); returns them with up to `halo` rows from the
-    previous / next rank attached (fewer at the scene borders).  Neighbour send/recv, one exchange per
-    scene.  Requires rows >= halo (one neighbour per side)."""
+def exchange_window(strip: torch.Tensor, strips: Sequence[Strip], group=None) -> torch.Tensor:
+    """Each rank holds only its own rows (B,C,y1-y0,W); returns its window [ty0, ty1) of `plan_strips`: the rows it
+    lacks arrive from the previous / next rank.  Windows clamped at a scene border reach further into the one
+    neighbour they have (up to 2 x halo rows), so the sizes differ per edge; every rank derives all of them from the
+    shared plan.  Neighbour send/recv (xGMI links are point-to-point), one exchange per scene."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if strip.shape[2] < halo:
-        raise ValueError("strip shorter than the halo: use fewer ranks or a smaller halo")
+    s = strips[rank]
+    need_top, need_bot = s.y0 - s.ty0, s.ty1 - s.y1
+
+    def rows_needed_by(r):     # (rows rank r needs from r-1, rows it needs from r+1)
+        t = strips[r]
+        return t.y0 - t.ty0, t.ty1 - t.y1
+
     ops, top, bot = [], None, None
+    B, C, rows, W = strip.shape
     if rank > 0:
-        top = torch.empty_like(strip[:, :, :halo])
-        ops += [dist.P2POp(dist.isend, strip[:, :, :halo].contiguous(), rank - 1, group),
-                dist.P2POp(dist.irecv, top, rank - 1, group)]
+        give = rows_needed_by(rank - 1)[1]                 # what the previous rank needs from the top of mine
+        if give > rows or need_top > strips[rank - 1].y1 - strips[rank - 1].y0:
+            raise ValueError("exchange_window: a window spans more than one neighbour; use fewer ranks or a smaller halo")
+        if give:
+            ops.append(dist.P2POp(dist.isend, strip[:, :, :give].contiguous(), rank - 1, group))
+        if need_top:
+            top = strip.new_empty((B, C, need_top, W))
+            ops.append(dist.P2POp(dist.irecv, top, rank - 1, group))
     if rank < world - 1:
-        bot = torch.empty_like(strip[:, :, :halo])
-        ops += [dist.P2POp(dist.isend, strip[:, :, -halo:].contiguous(), rank + 1, group),
-                dist.P2POp(dist.irecv, bot, rank + 1, group)]
+        give = rows_needed_by(rank + 1)[0]
+        if give > rows or need_bot > strips[rank + 1].y1 - strips[rank + 1].y0:
+            raise ValueError("exchange_window: a window spans more than one neighbour; use fewer ranks or a smaller halo")
+        if give:
+            ops.append(dist.P2POp(dist.isend, strip[:, :, rows - give:].contiguous(), rank + 1, group))
+        if need_bot:
+            bot = strip.new_empty((B, C, need_bot, W))
+            ops.append(dist.P2POp(dist.irecv, bot, rank + 1, group))
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
     return torch.cat([t for t in (top, strip, bot) if t is not None], 2)
+
+
+def exchange_halo(strip: torch.Tensor, halo: int, group=None) -> torch.Tensor:
+    """Symmetric special case: up to `halo` rows from each neighbour (fewer at the scene borders)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rows = strip.shape[2]
+    if rows < halo:
+        raise ValueError("strip shorter than the halo: use fewer ranks or a smaller halo")
+    H = rows * world
+    strips = [Strip(r * rows, (r + 1) * rows, max(0, r * rows - halo), min(H, (r + 1) * rows + halo), H) for r in range(world)]
+    return exchange_window(strip, strips, group)

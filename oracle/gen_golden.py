@@ -145,8 +145,8 @@ def gen_model(ref_jspsr, path, in_channels, nf, B, H, W, seed, training):
         "pred": pred.detach().numpy(), "loss": np.float64(loss.item()),
         "seed": np.int64(seed), "nf": np.int64(nf), "BHW": np.array([B, H, W]),
         "training": np.bool_(training),
-        "param_abs_sum": np.float64(sum(v.double().abs().sum().item() for k, v in sd.items())),
-        "input_abs_sum": np.float64(sum(t.abs().sum().item() for t in inputs) + gt.abs().sum().item()),
+        "param_checksum": np.float64(R.checksum(sd.values())),
+        "input_checksum": np.float64(R.checksum(list(inputs) + [gt])),
     }
     if training:
         loss_smooth.backward()
@@ -203,7 +203,8 @@ def gen_lrru(path, B, H, W, seed, training):
     loss = ((pred - gt) ** 2).mean()
     store = {"pred": pred.detach().numpy(), "loss": np.float64(loss.item()), "seed": np.int64(seed),
              "BHW": np.array([B, H, W]), "training": np.bool_(training),
-             "param_abs_sum": np.float64(sum(v.double().abs().sum().item() for v in sd.values()))}
+             "param_checksum": np.float64(R.checksum(sd.values())),
+             "input_checksum": np.float64(R.checksum(list(inputs) + [gt]))}
     if training:
         (pred * R.probe_gradient(pred.shape, seed + 2)).mean().backward()
         _store_grads(model, store, ("weight_offset3.conv_weight.weight", "Post_process.w", "weight_offset3.convf1.conv.0.weight"))
@@ -227,7 +228,8 @@ def gen_edsr(path, B, H, W, seed, training):
     loss = ((pred - gt) ** 2).mean()
     store = {"pred": pred.detach().numpy(), "loss": np.float64(loss.item()), "seed": np.int64(seed),
              "BHW": np.array([B, H, W]), "training": np.bool_(training),
-             "param_abs_sum": np.float64(sum(v.double().abs().sum().item() for v in sd.values()))}
+             "param_checksum": np.float64(R.checksum(sd.values())),
+             "input_checksum": np.float64(R.checksum(list(inputs) + [gt]))}
     if training:
         (pred * R.probe_gradient(pred.shape, seed + 2)).mean().backward()
         _store_grads(model, store, ("entry.weight", "generator.conv_weight.0.weight", "post_layer.w"))
@@ -235,10 +237,134 @@ def gen_edsr(path, B, H, W, seed, training):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_init_stream(ref_jspsr, path, in_channels, nf, seed):
+    """a11: the reference's `_initialize_weights` (models/JSPSR.py:494-517) under np.random.seed(seed).  The product
+    module must draw the same stream (same module order, same scipy sampler): compared here bit for bit against the
+    imported reference, and summarised (per-tensor sum / abs-sum / first and last values) for the box without it."""
+    from jspsr_amd.JSPSR import Model
+    np.random.seed(seed)
+    ref = ref_jspsr.Model(in_channels=dict(in_channels, COP30=1), out_channels=1, num_feature=nf,
+                          layers=(2, 2, 2, 2), spn=True, spn_scale=1.0).state_dict()
+    np.random.seed(seed)
+    mine = Model(dict(in_channels, COP30=1), num_feature=nf).state_dict()
+    assert list(ref) == list(mine), "state_dict key order differs"
+    for k in ref:
+        assert ref[k].dtype == mine[k].dtype and torch.equal(ref[k], mine[k]), f"init stream differs at {k}"
+    names = list(ref)
+    summ = np.zeros((len(names), 4))
+    for i, k in enumerate(names):
+        t = ref[k].double().reshape(-1)
+        summ[i] = (t.sum().item(), t.abs().sum().item(), t[0].item(), t[-1].item())
+    np.savez(path, names=np.array(names), summary=summ, seed=np.int64(seed), nf=np.int64(nf),
+             with_mask=np.bool_("mask" in in_channels))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB (reference init == product init, bit for bit,", len(names), "tensors)")
+
+
+def gen_host_side(path):
+    """g7: the rows either side of the hot path, made by the reference's own code where that code
+    runs here: evaluation.metrics Meter{RMSE,Median,NMAD,LE95} (package "local": torch only; metrics.py:338-590 incl.
+    MeterBase._prepare :147-199), data.data_utils ToTensor.scale_data / ToDEM.descale_data (:289-312,:441-457) and
+    TileCrop (:87-194), losses.loss_schemes.MultiLoss over torch's L1Loss/MSELoss (:6-12,:55-72).
+    Their files import packages this image lacks (piq, skimage, kornia, richdem, hide_warnings, affine); those names are
+    bound to EMPTY placeholder modules so the import statement succeeds -- none of the functions exercised below
+    touches them (a call into a placeholder would raise AttributeError).  What does need them stays unpinned and is
+    NOT generated here: MeterPSNR (piq.psnr), EdgeLoss (kornia spatial_gradient), MeterSlope (richdem)."""
+    for name in ("piq", "skimage", "skimage.metrics", "kornia", "kornia.filters", "richdem", "hide_warnings", "affine"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage"].metrics = sys.modules["skimage.metrics"]
+    sys.modules["kornia"].filters = sys.modules["kornia.filters"]
+    sys.modules["kornia.filters"].spatial_gradient = None        # `from kornia.filters import spatial_gradient`
+    sys.modules["hide_warnings"].hide_warnings = lambda f=None, **k: (f if f is not None else (lambda g: g))
+    sys.modules["affine"].Affine = None
+    sys.modules["piq"].ssim = None
+    import data.data_utils as du
+    import evaluation.metrics as em
+    import losses.loss_schemes as ls
+
+    rs = np.random.RandomState(77)
+    vmin, vmax = -80.0, 929.0
+    store = {"vmin": vmin, "vmax": vmax}
+    # --- scaling (torch and numpy branches of the reference) ---
+    z = torch.from_numpy(rs.uniform(-60.0, 850.0, (1, 1, 100, 120))).float()
+    for lg in (False, True):
+        tag = "log" if lg else "lin"
+        sc = du.ToTensor.scale_data(z.clone(), torch.tensor(vmin) if lg else vmin, torch.tensor(vmax) if lg else vmax, lg)
+        store[f"scale_{tag}"] = sc.numpy()
+        store[f"scale_np_{tag}"] = du.ToTensor.scale_data(z.numpy().copy(), vmin, vmax, lg, base_elev=3.5)
+        store[f"descale_{tag}"] = du.ToDEM.descale_data(sc.clone(), vmin, vmax, lg).numpy()
+    store["z"] = z.numpy()
+    # --- meters: one tile per update (the reference evaluates with batch size 1), three tiles ---
+    preds, gts = [], []
+    for i in range(3):
+        zz = torch.from_numpy(rs.uniform(-40.0, 600.0, (1, 1, 100, 120))).float()
+        gt = du.ToTensor.scale_data(zz, torch.tensor(vmin), torch.tensor(vmax), True)
+        noisy = (zz + torch.from_numpy(rs.standard_normal(tuple(zz.shape))).float() * (1.0 + i)).clamp_min(-70.0)
+        pred = du.ToTensor.scale_data(noisy, torch.tensor(vmin), torch.tensor(vmax), True)
+        pred[0, 0, 50, 60 + i] = 1.7       # exercised by _prepare's clamp
+        pred[0, 0, 2, 3] = -0.2            # inside the cropped border
+        preds.append(pred)
+        gts.append(gt)
+    store["meter_pred"] = torch.cat(preds).numpy()
+    store["meter_gt"] = torch.cat(gts).numpy()
+    meta = [{"subset": "train_a", "id": "x-y-12-34"}]
+    for border in (0.05, 0.0):
+        for lg in (True, False):
+            meters = {"RMSE": em.MeterRMSE("local", border=border, value_min=vmin, value_max=vmax, verbose=False),
+                      "Median": em.MeterMedian("local", border=border, value_min=vmin, value_max=vmax, verbose=False),
+                      "NMAD": em.MeterNMAD("local", border=border, value_min=vmin, value_max=vmax, verbose=False),
+                      "LE95": em.MeterLE95("local", border=border, value_min=vmin, value_max=vmax, verbose=False)}
+            for pred, gt in zip(preds, gts):
+                for m in meters.values():
+                    m.update(pred, gt, meta=meta, base_elev=0, elev_log=lg)
+            for k, m in meters.items():
+                store[f"score_{k}_b{int(border * 100)}_{'log' if lg else 'lin'}"] = np.float64(m.get_score())
+    # --- TileCrop: window walk over a 334-px sample (9 tiles, stride 103) and a 192-px one (4 tiles) ---
+    for full, k, n in ((334, 128, 9), (192, 128, 4), (70, 32, 9)):
+        # pixel-index images: every value identifies its source pixel and channel (and the fixture compresses)
+        idx = (np.arange(full * full, dtype=np.int64).reshape(full, full, 1) * 4)
+        img = (idx + np.arange(3)).astype(np.float32)
+        dem = (idx + 3).astype(np.float32)
+        tc = du.TileCrop(crop_size=k, n_tile=n)
+        tiles_i, tiles_d = [], []
+        for _ in range(n):
+            out = tc({"image": img.copy(), "lr_dem": dem.copy()})
+            tiles_i.append(out["image"])
+            tiles_d.append(out["lr_dem"])
+        ti, td = np.stack(tiles_i).astype(np.int32), np.stack(tiles_d).astype(np.int32)
+        if full > 100:      # the big covers: the four corner pixels of every tile identify its window
+            ti, td = ti[:, ::k - 1, ::k - 1], td[:, ::k - 1, ::k - 1]
+        store[f"tiles_img_{full}"], store[f"tiles_dem_{full}"] = ti, td
+        store[f"tile_params_{full}"] = np.array(du.TileCrop.get_tile(full, k, n))
+    store["tile_params_322_116"] = np.array(du.TileCrop.get_tile(322, 116))
+    store["tile_params_256_128"] = np.array(du.TileCrop.get_tile(256, 128))
+    # --- MultiLoss bookkeeping with the two torch-only terms (the Sobel term needs kornia: unpinned) ---
+    crit = ls.MultiLoss(L1={"loss_fn": ls.get_loss("l1"), "weight": 1.0}, L2={"loss_fn": ls.get_loss("l2"), "weight": 1.0})
+    p64, g64 = torch.cat(preds).double().requires_grad_(), torch.cat(gts).double()
+    out = crit(p64, g64)
+    out["Total"].backward()
+    store["loss_L1"], store["loss_L2"], store["loss_Total_L1L2"] = (np.float64(out[k].item()) for k in ("L1", "L2", "Total"))
+    store["loss_grad_L1L2"] = p64.grad.numpy()
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref_jspsr, ref_spn = import_reference()
     out = os.path.join(REPO, "tests", "golden")
     os.makedirs(out, exist_ok=True)
+    only = set(sys.argv[1:])
+
+    def want(name):
+        return not only or any(o in name for o in only)
+
+    if want("g0_init"):
+        gen_init_stream(ref_jspsr, os.path.join(out, "g0_init_stream_msk_nf8.npz"), {"lr_dem": 1, "image": 3, "mask": 15}, 8, 7)
+        gen_init_stream(ref_jspsr, os.path.join(out, "g0_init_stream_img_nf32.npz"), {"lr_dem": 1, "image": 3}, 32, 8)
+    if want("g7"):
+        gen_host_side(os.path.join(out, "g7_host_side.npz"))
+    if not want("g1") and not want("g3") and not want("g4") and not want("g5") and not want("g6"):
+        return
     gen_prop(ref_spn, os.path.join(out, "g1_postprocessor.npz"))
     img = {"lr_dem": 1, "image": 3}
     msk = {"lr_dem": 1, "image": 3, "mask": 15}
@@ -247,6 +373,8 @@ def main():
     gen_model(ref_jspsr, os.path.join(out, "g3_img_nf8_b2_48x80_train.npz"), img, 8, 2, 48, 80, 12, True)
     gen_model(ref_jspsr, os.path.join(out, "g4_msk_nf8_b2_64_train.npz"), msk, 8, 2, 64, 64, 13, True)
     gen_model(ref_jspsr, os.path.join(out, "g4_msk_nf8_b2_64_eval.npz"), msk, 8, 2, 64, 64, 13, False)
+    # the benched architecture (image+mask, num_feature 32: 1536 / 1024-channel decoder layers), training mode
+    gen_model(ref_jspsr, os.path.join(out, "g4_msk_nf32_b1_64_train.npz"), msk, 32, 1, 64, 64, 14, True)
     gen_lrru(os.path.join(out, "g5_lrru_b1_64_train.npz"), 1, 64, 64, 21, True)
     gen_lrru(os.path.join(out, "g5_lrru_b2_32x48_eval.npz"), 2, 32, 48, 22, False)
     gen_edsr(os.path.join(out, "g6_edsr_b2_40x56_train.npz"), 2, 40, 56, 31, True)

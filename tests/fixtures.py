@@ -1,0 +1,85 @@
+"""Shared fixture plumbing for the parity tests (test infrastructure).
+
+The fixtures under tests/golden/ were produced by the reference's own modules (oracle/gen_golden.py) on
+parameters and inputs drawn from numpy's frozen legacy RandomState stream; a fixture stores the seed and
+an order-sensitive checksum of what that seed must regenerate.  A mismatch is a hard FAILURE (never a skip):
+a silently skipped fixture test would read as green while pinning nothing.
+"""
+import os
+
+import numpy as np
+import torch
+
+from oracle import jspsr_ref as R
+
+IMG = {"lr_dem": 1, "image": 3}
+MSK = {"lr_dem": 1, "image": 3, "mask": 15}
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def regen(z, shapes, with_mask):
+    """(state_dict fp64, inputs fp64, target fp64) of fixture `z`; fails loudly if the stream moved."""
+    seed = int(z["seed"])
+    B, H, W = (int(v) for v in z["BHW"])
+    sd = R.make_state_dict(shapes, seed, torch.float64)
+    inputs, gt = R.synthetic_batch(B, H, W, with_mask, seed=seed + 1, dtype=torch.float64)
+    c1, c2 = R.checksum(sd.values()), R.checksum(list(inputs) + [gt])
+    assert abs(c1 - float(z["param_checksum"])) <= 1e-9 * abs(c1), \
+        "fixture parameters do not regenerate (numpy RandomState stream / erfinv changed?): rerun oracle/gen_golden.py"
+    assert abs(c2 - float(z["input_checksum"])) <= 1e-9 * abs(c2), \
+        "fixture inputs do not regenerate: rerun oracle/gen_golden.py"
+    return sd, inputs, gt
+
+
+def regen_jspsr(z, in_channels):
+    return regen(z, R.jspsr_param_shapes(in_channels, int(z["nf"])), "mask" in in_channels)
+
+
+def as_f32(sd):
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def oracle_gradients(forward, sd, inputs, probe, dtype=torch.float64):
+    """Parameter gradients of mean(pred * probe) from the CPU oracle in `dtype` -> (pred, {name: grad})."""
+    cast = lambda v: v.detach().to(dtype) if v.is_floating_point() else v.clone()
+    sd = {k: cast(v) for k, v in sd.items()}
+    params = {k: v.requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    sd.update(params)
+    pred = forward(sd, [cast(t) for t in inputs])
+    (pred * probe.to(dtype)).mean().backward()
+    return pred.detach(), {k: v.grad.detach().double() for k, v in params.items() if v.grad is not None}
+
+
+def gradient_noise_floor(forward, sd, inputs, probe, g_ref, n_trials=2):
+    """Per-parameter relative gradient change the ORACLE ITSELF shows under fp32-sized disturbances -- the
+    floor below which a gradient comparison against an fp32 implementation carries no information (every
+    ReLU whose pre-activation sits within rounding of zero may flip, and a flipped mask changes gradient
+    entries by O(1)).  Two measurements, max of both per parameter:
+      (a) fp64 oracle with every floating input and parameter multiplied by (1 + 2^-23 u), u ~ U(-1,1)
+          (an fp32 rounding of the operands), `n_trials` draws;
+      (b) the oracle evaluated in fp32 end to end (torch CPU kernels: another fp32 implementation of the
+          same formulae, rounding at every layer as any fp32 implementation must).
+    Returns {name: (norm_floor, tensor_floor)}: relative change of the gradient norm, and relative L2 change
+    of the gradient tensor."""
+    floors = {k: [0.0, 0.0] for k in g_ref}
+
+    def fold(g):
+        for k, ref in g_ref.items():
+            n = ref.norm().item()
+            floors[k][0] = max(floors[k][0], abs(g[k].norm().item() - n) / max(n, 1e-30))
+            floors[k][1] = max(floors[k][1], (g[k] - ref).norm().item() / max(n, 1e-30))
+
+    for t in range(n_trials):
+        rs = np.random.RandomState(1000 + t)
+        jig = lambda v: v * (1 + 2.0 ** -23 * torch.from_numpy(rs.uniform(-1, 1, tuple(v.shape)))) if v.is_floating_point() else v
+        fold(oracle_gradients(forward, {k: jig(v) for k, v in sd.items()}, [jig(x) for x in inputs], probe)[1])
+    fold(oracle_gradients(forward, sd, inputs, probe, torch.float32)[1])
+    return {k: tuple(v) for k, v in floors.items()}

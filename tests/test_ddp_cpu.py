@@ -33,7 +33,9 @@ def _worker(rank, world, port, q):
         sl = slice(rank * 2, rank * 2 + 2)
         ((net(x[sl]) - y[sl]) ** 2).mean().backward()
         red.finish()
-    q.put((rank, [p.grad.clone() for p in net.parameters()], [p.detach().clone() for p in net.parameters()], len(red.buckets)))
+    # numpy arrays travel by value (tensors travel as shared-memory handles that die with this process)
+    q.put((rank, [p.grad.numpy().copy() for p in net.parameters()], [p.detach().numpy().copy() for p in net.parameters()],
+           len(red.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +51,8 @@ def test_gradreducer_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, g0, w0, nb), (_, g1, w1, _) = res
+    (_, g0, w0, nb), (_, g1, w1, _) = [(r, [torch.from_numpy(a) for a in g], [torch.from_numpy(a) for a in w], n)
+                                       for r, g, w, n in res]
     assert nb > 1
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)
@@ -66,3 +69,76 @@ def test_gradreducer_world2_gloo():
     ((net(x) - y) ** 2).mean().backward()
     for p, a in zip(net.parameters(), g0):
         assert torch.allclose(p.grad, a, atol=1e-6)
+
+
+class _Work:
+    def wait(self):
+        return True
+
+
+def _stub_reducer(monkeypatch, world=2, bucket_bytes=64):
+    from jspsr_amd.ddp import GradReducer
+    calls = []
+    monkeypatch.setattr(dist, "all_reduce", lambda t, op=None, group=None, async_op=False: (calls.append(t.numel()), _Work())[1])
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 1, 3, padding=1))
+    red = GradReducer(net.parameters(), bucket_bytes=bucket_bytes, world=world)
+    x = torch.randn(2, 2, 8, 8)
+    return net, red, x, calls
+
+
+def test_backward_before_first_zero_grad_is_counted(monkeypatch):
+    """The bucket counters start from the bucket sizes: a backward pass issued before the first reducer.zero_grad()
+    reduces every bucket exactly once (they used to start at zero and go negative: nothing was reduced, silently)."""
+    net, red, x, calls = _stub_reducer(monkeypatch)
+    net(x).mean().backward()
+    assert len(calls) == len(red.buckets) and all(v == 0 for v in red._pending)
+    red.finish()
+    with pytest.raises(RuntimeError, match="exactly once per step"):
+        red.finish()          # a second finish() would divide by the world size again
+
+
+def test_dropped_gradient_aliases_are_an_error_not_a_silent_zero_step(monkeypatch):
+    """The reference's loop calls model.zero_grad(set_to_none=True) (train/train_utils.py:210).  If that drops the
+    aliases into the flat buffer, autograd allocates fresh .grad tensors and the flat buffer (what is all-reduced and
+    what FlatAdamW reads) stays zero: finish() must refuse, and reducer.zero_grad() must restore the aliases."""
+    net, red, x, calls = _stub_reducer(monkeypatch)
+    red.zero_grad()
+    net.zero_grad(set_to_none=True)
+    net(x).mean().backward()
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        red.finish()
+    red.zero_grad()           # re-aliases
+    net(x).mean().backward()
+    red.finish()
+    assert all(p.grad.data_ptr() >= red.flat.data_ptr() for p in net.parameters()) and red.flat.abs().sum() > 0
+
+
+def test_attached_module_zero_grad_keeps_the_aliases(monkeypatch):
+    from jspsr_amd.blocks import HotPathModule
+    from jspsr_amd.ddp import GradReducer
+
+    class Net(HotPathModule):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(2, 1, 3, padding=1)
+
+        def forward(self, x):
+            return self.c(x)
+
+    net = Net()
+    red = GradReducer(net.parameters(), world=1).attach(net)
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)       # what the reference's loop does
+        net(torch.randn(1, 2, 4, 4)).mean().backward()
+        red.finish()
+        assert red.flat.abs().sum() > 0 and net.c.weight.grad.data_ptr() == red.flat.data_ptr() + 4 * net.c.bias.numel()
+
+
+def test_shared_layer_with_direct_gradients_is_refused(monkeypatch):
+    net, red, x, calls = _stub_reducer(monkeypatch)
+    p = next(net.parameters())
+    red.zero_grad()
+    p._jspsr_grad_ready(p)
+    with pytest.raises(RuntimeError, match="more than once"):
+        p._jspsr_grad_ready(p)

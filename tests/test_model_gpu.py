@@ -1,6 +1,4 @@
 """GPU parity: the product Model (HIP path) against the reference-made fixtures and the oracle."""
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -8,42 +6,37 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import jspsr_ref as R
+from tests import fixtures as Fx
 
-IMG = {"lr_dem": 1, "image": 3}
-MSK = {"lr_dem": 1, "image": 3, "mask": 15}
+IMG, MSK = Fx.IMG, Fx.MSK
 CASES = [
     ("g3_img_nf32_64_train.npz", IMG),
     ("g3_img_nf32_64_eval.npz", IMG),
     ("g3_img_nf8_b2_48x80_train.npz", IMG),
     ("g4_msk_nf8_b2_64_train.npz", MSK),
     ("g4_msk_nf8_b2_64_eval.npz", MSK),
+    ("g4_msk_nf32_b1_64_train.npz", MSK),     # the benched architecture: image+mask, num_feature 32
 ]
 
 
 def _build(z, ic):
     from jspsr_amd.JSPSR import Model
-    nf, seed = int(z["nf"]), int(z["seed"])
-    B, H, W = (int(v) for v in z["BHW"])
-    sd = R.make_state_dict(R.jspsr_param_shapes(ic, nf), seed, torch.float64)
-    inputs, gt = R.synthetic_batch(B, H, W, "mask" in ic, seed=seed + 1, dtype=torch.float64)
-    s1 = sum(v.double().abs().sum().item() for v in sd.values())
-    if abs(s1 - float(z["param_abs_sum"])) > 1e-9 * s1:
-        pytest.skip("torch CPU generator stream differs from the fixture's")
-    m = Model(dict(ic, COP30=1), num_feature=nf)
-    m.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()})
-    return m.cuda(), [t.float().cuda() for t in inputs], gt.float().cuda()
+    sd, inputs, gt = Fx.regen_jspsr(z, ic)        # fails (never skips) if the fixture does not regenerate
+    m = Model(dict(ic, COP30=1), num_feature=int(z["nf"]))
+    m.load_state_dict(Fx.as_f32(sd))
+    return m.cuda(), [t.float().cuda() for t in inputs], gt.float().cuda(), (sd, inputs)
 
 
-def _rel(a, b):
-    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
-    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+_rel = Fx.rel
 
 
 @pytest.mark.parametrize("name,ic", CASES)
 def test_model_matches_reference_fixture(golden_dir, name, ic):
-    """north_star tolerance: 1e-4 relative (fp32) against the reference's CPU result."""
-    z = np.load(os.path.join(golden_dir, name))
-    m, inputs, gt = _build(z, ic)
+    """north_star tolerance: 1e-4 relative (fp32) against the reference's CPU result.  Gradients: every parameter,
+    element-wise, against the fp64 oracle (itself held to the fixture at 1e-8 by test_oracle_golden.py and re-checked
+    here), within a tolerance DERIVED IN THIS TEST from the oracle's own sensitivity to fp32-sized disturbances."""
+    z = Fx.load(golden_dir, name)
+    m, inputs, gt, (sd64, in64) = _build(z, ic)
     training = bool(z["training"])
     m.train(training)
     pred = m(*inputs)
@@ -52,7 +45,7 @@ def test_model_matches_reference_fixture(golden_dir, name, ic):
     assert (pred.detach().cpu().double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
     if not training:
         # inference path proper: under no_grad every conv -> BatchNorm(eval) (-> + shortcut) (-> ReLU) is one launch
-        # with the normalisation folded into the conv epilogue (ops.conv_bn_infer) -- same bound, fp32 and bf16
+        # with the normalisation folded into the conv epilogue (ops.conv_bn_infer) -- same bound in fp32
         with torch.no_grad():
             pred_i = m(*inputs)
         assert (pred_i.cpu().double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
@@ -63,25 +56,78 @@ def test_model_matches_reference_fixture(golden_dir, name, ic):
         return
     loss = (pred - gt).abs().mean() + ((pred - gt) ** 2).mean()
     assert abs(loss.item() - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
-    (pred * R.probe_gradient(pred.shape, int(z["seed"]) + 2, torch.float32).cuda()).mean().backward()   # fixed linear probe
-    grads = dict(m.named_parameters())
-    # Whole-model gradients have a noise floor that no fp32 implementation can beat: a forward difference of
-    # ~5e-6 flips the ReLU mask of every activation that close to zero, and flipping a fraction f of the masks
-    # perturbs a gradient by ~sqrt(f) (the fp64 oracle itself moves 0.3-3 % under a 1e-6 input perturbation).
-    # The backward kernels are checked to 1e-5..1e-6 per operator (test_conv_gpu, test_elementwise_gpu,
-    # test_prop_gpu); here every one of the parameter gradients must agree within that floor.
-    errs = []
+    probe = R.probe_gradient(pred.shape, int(z["seed"]) + 2)                                             # fixed linear probe
+    (pred * probe.float().cuda()).mean().backward()
+    grads = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
+    # fp64 oracle gradients of every parameter; chain of trust to the reference: its gradient norms and stored tensors
+    fwd = lambda sd_, inp: R.jspsr_forward(sd_, inp, True)
+    _, g_ref = Fx.oracle_gradients(fwd, sd64, in64, probe)
     for k, n in zip(z["grad_names"], z["grad_norms"]):
-        got = grads[str(k)].grad.double().norm().item()
-        errs.append(abs(got - n) / max(n, 1e-12))
-    errs = np.array(errs)
-    assert errs.max() < 5e-2 and np.median(errs) < 5e-3, (errs.max(), np.median(errs))
+        assert abs(g_ref[str(k)].norm().item() - n) <= 1e-8 * max(n, 1e-30) + 1e-13, k
+    # Measured noise floor (tests/fixtures.py::gradient_noise_floor): how far the ORACLE's gradient of each parameter
+    # moves under (a) an fp32 rounding of inputs and parameters and (b) evaluation in fp32 -- ReLU masks within
+    # rounding of zero flip, and each flip changes gradient entries by O(1).  The HIP gradient must sit within
+    # 4x that floor (+1e-5 for parameters whose floor is ~0: tap weights, last-layer biases), parameter by parameter.
+    floor = Fx.gradient_noise_floor(fwd, sd64, in64, probe, g_ref)
+    worst = []
+    for k, ref_g in g_ref.items():
+        err = _rel(grads[k], ref_g)
+        tol = 4.0 * floor[k][1] + 1e-5
+        worst.append((err / tol, k, err, floor[k][1]))
+    worst.sort(reverse=True)
+    print(f"{name}: worst gradient error / derived tolerance: " + "; ".join(f"{k} {e:.2e}/{4 * f + 1e-5:.2e}" for _, k, e, f in worst[:4]))
+    assert worst[0][0] < 1.0, worst[:5]
     for k in z.files:
-        if k.startswith("grad:"):
-            tol = 2e-3 if k[5:] in ("postprocessor.w", "postprocessor.b", "generator.conv_weight.0.bias") else 5e-2
-            assert _rel(grads[k[5:]].grad, z[k]) < tol, k
         if k.startswith("buf:"):
             assert _rel(m.state_dict()[k[4:]], z[k]) < 1e-4, k
+
+
+def test_benched_configuration_bf16_training_step(golden_dir):
+    """The benchmarked path -- image+mask, num_feature 32, bf16 storage / fp32 accumulate, TRAINING mode -- against the
+    reference-made fixture.  bf16 cannot meet 1e-4: every stored activation is rounded to 8 significant bits
+    (2^-9 = 0.2 % relative), so the bound is stated here and, as SURVEY section 7 prescribes, the comparison that
+    counts is at the level of the evaluation scores.  Stated tolerances (bf16 vs the fp64 reference):
+      * prediction: max |diff| < 2e-2 x max|ref| and relative L2 < 5e-3;
+      * loss L1+L2: 5 % relative;
+      * evaluation scores through jspsr_amd.metrics on de-scaled elevations: |dRMSE| < 0.05 x RMSE(fp32) + 0.05 m,
+        |dPSNR| < 0.5 dB between the bf16 and the fp32 prediction of the same module;
+      * parameter gradients: the relative L2 error of the gradient of each of the 448 tensors < 0.25, median < 0.05
+        (bf16 rounding of the saved activations enters every weight gradient linearly: ~2^-9 x sqrt(depth)).
+    """
+    from jspsr_amd import metrics as M
+    z = Fx.load(golden_dir, "g4_msk_nf32_b1_64_train.npz")
+    m, inputs, gt, (sd64, in64) = _build(z, MSK)
+    m.train()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    ref = torch.from_numpy(z["pred"])
+    probe = R.probe_gradient(ref.shape, int(z["seed"]) + 2)
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m.load_state_dict(state)             # same running statistics going in
+        m.compute_dtype = dt
+        m.zero_grad(set_to_none=True)
+        pred = m(*inputs)
+        (pred * probe.float().cuda()).mean().backward()
+        out[dt] = (pred.detach(), {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()})
+    pb = out[torch.bfloat16][0].cpu().double()
+    assert (pb - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    assert _rel(pb, ref) < 5e-3
+    loss_b = ((pb - gt.cpu().double()).abs().mean() + ((pb - gt.cpu().double()) ** 2).mean()).item()
+    assert abs(loss_b - float(z["loss"])) < 5e-2 * float(z["loss"])
+    # scores on de-scaled elevations (configs/jspsr_r8_img_msk.yml: min -80, max 929, log scaling)
+    sc = {}
+    for dt in out:
+        meter = M.Meter(-80.0, 929.0, border=0.05, elev_log=True)
+        meter.update(out[dt][0], gt)
+        sc[dt] = meter.scores()
+    s32, s16 = sc[torch.float32], sc[torch.bfloat16]
+    print("scores fp32", s32, "bf16", s16)
+    assert abs(s16["RMSE"] - s32["RMSE"]) < 0.05 * s32["RMSE"] + 0.05
+    assert abs(s16["PSNR"] - s32["PSNR"]) < 0.5
+    _, g_ref = Fx.oracle_gradients(lambda sd_, inp: R.jspsr_forward(sd_, inp, True), sd64, in64, probe)
+    errs = np.array([_rel(out[torch.bfloat16][1][k], g_ref[k]) for k in g_ref])
+    print(f"bf16 gradient error over {errs.size} tensors: max {errs.max():.3e} median {np.median(errs):.3e}")
+    assert errs.max() < 0.25 and np.median(errs) < 0.05
 
 
 def test_generator_postprocessor_public_api():

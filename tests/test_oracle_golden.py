@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import jspsr_ref as R
+from tests import fixtures as Fx
 
 
 def _load(golden_dir, name):
@@ -109,19 +110,12 @@ MODEL_CASES = [
     ("g3_img_nf8_b2_48x80_train.npz", {"lr_dem": 1, "image": 3}),
     ("g4_msk_nf8_b2_64_train.npz", {"lr_dem": 1, "image": 3, "mask": 15}),
     ("g4_msk_nf8_b2_64_eval.npz", {"lr_dem": 1, "image": 3, "mask": 15}),
+    ("g4_msk_nf32_b1_64_train.npz", {"lr_dem": 1, "image": 3, "mask": 15}),   # the benched architecture
 ]
 
 
 def regen(z, in_channels, dtype):
-    nf, seed = int(z["nf"]), int(z["seed"])
-    B, H, W = (int(v) for v in z["BHW"])
-    shapes = R.jspsr_param_shapes(in_channels, nf)
-    sd = R.make_state_dict(shapes, seed, torch.float64)
-    inputs, gt = R.synthetic_batch(B, H, W, "mask" in in_channels, seed=seed + 1, dtype=torch.float64)
-    s1 = sum(v.double().abs().sum().item() for v in sd.values())
-    s2 = sum(t.abs().sum().item() for t in inputs) + gt.abs().sum().item()
-    if abs(s1 - float(z["param_abs_sum"])) > 1e-9 * s1 or abs(s2 - float(z["input_abs_sum"])) > 1e-9 * s2:
-        pytest.skip("torch CPU generator stream differs from the fixture's (different torch build)")
+    sd, inputs, gt = Fx.regen_jspsr(z, in_channels)      # fails (never skips) if the fixture does not regenerate
     cast = lambda v: v.to(dtype) if v.is_floating_point() else v
     return {k: cast(v) for k, v in sd.items()}, [cast(t) for t in inputs], cast(gt)
 
@@ -151,13 +145,18 @@ def test_model_fp64(golden_dir, name, in_channels):
 
 
 def test_config1_fp32_matches_reference_fp32(golden_dir):
-    """BASELINE config 1: fp32 restatement vs fp32 reference modules, 1e-6 abs on the output."""
+    """BASELINE config 1: fp32 restatement vs fp32 reference modules on the CPU.  Both are fp32 evaluations of the
+    same formulae in different operation orders; the yardstick is the reference's OWN fp32 rounding error against its
+    fp64 run (stored in the fixture, 1e-6 .. 6e-6 here): the restatement must sit within twice that of the fp32
+    reference and within 2e-5 of the fp64 one."""
     for name in ("g3_img_nf32_64_eval.npz", "g3_img_nf32_64_train.npz"):
         z = _load(golden_dir, name)
         sd, inputs, _ = regen(z, {"lr_dem": 1, "image": 3}, torch.float32)
         with torch.no_grad():
             pred = R.jspsr_forward(sd, inputs, bool(z["training"]))
-        assert (pred - _t(z["pred_fp32"])).abs().max().item() < 1e-6
+        ref_rounding = (_t(z["pred_fp32"]).double() - _t(z["pred"])).abs().max().item()
+        assert 1e-7 < ref_rounding < 1e-5
+        assert (pred - _t(z["pred_fp32"])).abs().max().item() < 2 * ref_rounding
         assert (pred.double() - _t(z["pred"])).abs().max().item() < 2e-5
 
 
@@ -169,14 +168,7 @@ def test_wrong_arity_raises():
 
 
 def _regen_simple(z, shapes, with_mask=False):
-    seed = int(z["seed"])
-    B, H, W = (int(v) for v in z["BHW"])
-    sd = R.make_state_dict(shapes, seed, torch.float64)
-    s1 = sum(v.double().abs().sum().item() for v in sd.values())
-    if abs(s1 - float(z["param_abs_sum"])) > 1e-9 * s1:
-        pytest.skip("torch CPU generator stream differs from the fixture's")
-    inputs, gt = R.synthetic_batch(B, H, W, with_mask, seed=seed + 1, dtype=torch.float64)
-    return sd, inputs, gt
+    return Fx.regen(z, shapes, with_mask)
 
 
 def _check_grads(z, params):

@@ -49,3 +49,37 @@ def test_exchange_halo_gloo_world3():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _worker_window(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jspsr_amd.tiling import exchange_window, plan_strips
+    H, halo = 96, 16
+    strips = plan_strips(H, world, halo)          # clamped equal windows: border ranks need 2*halo rows from one side
+    scene = torch.arange(2 * H * 5, dtype=torch.float32).reshape(1, 2, H, 5)
+    s = strips[rank]
+    got = exchange_window(scene[:, :, s.y0:s.y1].clone(), strips)
+    q.put((rank, bool(torch.equal(got, scene[:, :, s.ty0:s.ty1])), (s.y0 - s.ty0, s.ty1 - s.y1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_window_follows_the_strip_plan_gloo_world3():
+    """The composition the sharded forward uses: each rank owns only rows [y0,y1) and assembles the window
+    [ty0,ty1) of plan_strips (asymmetric at the scene borders) from its neighbours."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_window, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == (0, 32) and res[1][2] == (16, 16) and res[2][2] == (32, 0)   # 2*halo towards the only neighbour

@@ -40,3 +40,71 @@ def test_training_mode_is_rejected():
     x = [torch.rand(1, 1, 512, 64, device="cuda"), torch.rand(1, 3, 512, 64, device="cuda")]
     with pytest.raises(RuntimeError, match="eval"):
         tiling.emulate_sharded_forward(m, x, 2)
+
+
+def _model_and_scene(H=1024, W=256):
+    from jspsr_amd.JSPSR import Model
+    ic = {"lr_dem": 1, "image": 3, "mask": 15}
+    sd = R.make_state_dict(R.jspsr_param_shapes(ic, 8), seed=3)
+    m = Model(dict(ic, COP30=1), num_feature=8)
+    m.load_state_dict(sd)
+    inputs, _ = R.synthetic_batch(1, H, W, True, seed=4)
+    return m.cuda().eval(), inputs
+
+
+def _rank_owning_only_its_rows(rank, world, port, outdir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # two ranks on ONE card: RCCL refuses that, gloo does not
+    from jspsr_amd import tiling
+    m, inputs = _model_and_scene()
+    H = inputs[0].shape[2]
+    s = tiling.plan_strips(H, world, 128)[rank]
+    own = [t[:, :, s.y0:s.y1].contiguous().cuda() for t in inputs]   # this rank never sees another row of the scene
+    del inputs
+    out, reach = tiling.sharded_forward_owned(m, own, H, halo=128, return_reach=True)
+    torch.save((s.y0, s.y1, out.cpu(), reach), os.path.join(outdir, f"rank{rank}.pt"))
+    # a halo that cannot hold receptive radius + offset reach must be refused, not silently wrong
+    try:
+        tiling.sharded_forward_owned(m, own, H, halo=32)   # 2 ranks: 64 rows towards the one neighbour < 97
+        refused = False
+    except tiling.HaloTooSmall:
+        refused = True
+    torch.save(refused, os.path.join(outdir, f"refused{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_each_owning_only_its_strip_match_monolithic(tmp_path):
+    """The real cross-process path of config 5: exchange_window (neighbour send/recv) composed with the
+    sharded forward and the cross-rank gate-statistics all-reduce (_combine_ranks), two ranks over gloo."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_owning_only_its_rows, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.kill()
+    assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    m, inputs = _model_and_scene()
+    with torch.no_grad():
+        mono = m(*[t.cuda() for t in inputs]).cpu()
+    parts = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == mono.shape[2]
+    got = torch.cat([p[2] for p in parts], 2)
+    assert (got - mono).abs().max().item() < 2e-5
+    from jspsr_amd import tiling
+    for _, _, _, reach in parts:          # the asserted condition of SURVEY 8e: max|offset| <= halo - 97
+        assert 0 < reach <= 128 - tiling.RECEPTIVE_RADIUS
+    assert all(torch.load(os.path.join(tmp_path, f"refused{r}.pt")) for r in range(2))
