@@ -73,6 +73,28 @@ int jspsr_prop_backward_f32(const float* grad_out, const float* dem, const float
 int jspsr_prop_backward_fold_f32(const void* workspace, int B, int H, int W, float* grad_wk, float* grad_b0,
                                  jspsr_stream_t stream);
 
+/* ---- K1h: the same propagation step fed straight from the generator head's NHWC output ----------------------
+ * Inside the models the two 1x1 heads of Generator.forward (models/components/spn.py:41-52,66-68; LRRU.py:238-247) run
+ * as ONE 32-channel convolution; these entry points read its output where it lies and fold in what the reference does
+ * between the heads and deform_conv2d: the Sigmoid of conv_weight (spn.py:43), the zero centre offset (spn.py:69-73),
+ * the mean subtraction (spn.py:100-101) and the residual (spn.py:116-117).  The public planar entries above stay the
+ * boundary of PostProcessor.forward.
+ *
+ * head [B][H][W][32], dtype JSPSR_F32 or JSPSR_BF16 (defined below), 16-byte aligned, channel c = 4 t + j:
+ *   t = 0..7 the learned taps in window order without the centre (k = t < 4 ? t : t + 1),
+ *   j = 0 affinity LOGIT of tap k (pre-sigmoid), j = 1 dy_k, j = 2 dx_k,
+ *   j = 3: the centre tap's affinity logit for t == 0; ignored for t > 0.
+ * dem, out [B][H][W] fp32; wk [9], b0 [1] as above.
+ * Backward: grad_head in the same layout and dtype = d/d(head) (sigmoid derivative included; channels 4t+3, t > 0,
+ * are written as zeros); grad_wk / grad_b0 overwritten, or both NULL to leave the per-workgroup partial rows in the
+ * workspace (jspsr_prop_head_backward_workspace_bytes; the fold is the 10-workgroup launch jspsr_prop_backward_f32 also uses). */
+int jspsr_prop_head_forward(int dtype, const float* dem, const void* head, const float* wk, const float* b0,
+                            float scale, float* out, int B, int H, int W, jspsr_stream_t stream);
+size_t jspsr_prop_head_backward_workspace_bytes(int B, int H, int W);
+int jspsr_prop_head_backward(int dtype, const float* grad_out, const float* dem, const void* head, const float* wk,
+                             void* grad_head, float* grad_wk, float* grad_b0, void* workspace, int B, int H, int W,
+                             jspsr_stream_t stream);
+
 /* ---- K2: convolutions on the matrix cores (implicit GEMM, NHWC) ---------------------------
  * Replace the reference's nn.Conv2d / nn.ConvTranspose2d calls and their autograd
  * (models/components/basics.py:6-20,39-47,69-77; every conv of models/JSPSR.py:66-180 and

@@ -67,5 +67,5 @@ class EDSR(HotPathModule):
                 h = blk(h)
             tail = self.encoder[-1]
             h = E.conv2d(h, tail.weight, tail.bias, 1, 1) + self.res_scale * xs
-            weight, off16 = self.generator.heads(self.generator.features(E.from_nchw(dem), h))
-            return self.post_layer(dem.float(), E.to_nchw_f32(weight), E.to_nchw_f32(off16))
+            head = self.generator.head(self.generator.features(E.from_nchw(dem), h))
+            return self.post_layer.from_head(dem.float(), head)

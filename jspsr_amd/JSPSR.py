@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
+from . import ops
 from .blocks import ConvUnit, HotPathModule, ResUnit, UpUnit
 from .spn import Generator, PostProcessor
 
@@ -217,8 +218,9 @@ class Model(HotPathModule):
             x = buf.join([up(x, dest=(buf, 0))] + joined[s], 0, defer=nb if defer_skip else 0)
         c0 = self.conv0(x)
         dem = dem.detach()  # :372
-        weight, off16 = self.generator.heads(self.generator.features(dem_a.detach(), c0))
+        head = self.generator.head(self.generator.features(dem_a.detach(), c0))
         if E._offset_probe is not None:
-            E._offset_probe.append(off16)
-        # K1 reads planar fp32 operands; 16-channel offsets: the zero centre pair is implicit
-        return self.postprocessor(dem.float(), E.to_nchw_f32(weight), E.to_nchw_f32(off16))
+            E._offset_probe.append(ops.split_head(head)[1])
+        # K1h reads the merged head's NHWC output where it lies (sigmoid, zero centre offset, mean subtraction,
+        # gather, residual: one kernel; its backward writes the head's gradient in the same layout)
+        return self.postprocessor.from_head(dem.float(), head)

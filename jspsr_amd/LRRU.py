@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
+from . import ops
 from .blocks import ConvUnit, HotPathModule, ResUnit
 from .JSPSR import Model as _JSPSR
 
@@ -64,6 +65,16 @@ class DepthEncoder(nn.Module):
         x = self.ref(self.conv(E.cat((d, f))))
         weight = E.sigmoid(E.conv2d(x, self.conv_weight.weight, self.conv_weight.bias))
         return weight, E.conv2d(x, self.conv_offset.weight, self.conv_offset.bias)
+
+    def head(self, depth, context):
+        """Same features, the two 1x1 heads as one tap-major 32-channel convolution (affinity logits + offsets) for
+        the head-fed propagation kernel (ops.merge_heads / ops.propagate_head)."""
+        d = self.convd2(self.convd1(depth))
+        f = self.convf2(self.convf1(context))
+        x = self.ref(self.conv(E.cat((d, f))))
+        w_all, b_all = ops.merge_heads(self.conv_weight.weight, self.conv_weight.bias, self.conv_offset.weight,
+                                       self.conv_offset.bias)
+        return E.conv2d(x, w_all, b_all)
 
 
 class PostProcess(nn.Module):
@@ -140,8 +151,8 @@ class Model(HotPathModule):
     def _step(self, current, context, enc):
         """One propagation step on the detached running estimate (LRRU.py:453-455 etc.)."""
         current = current.detach().float().contiguous()
-        weight, off16 = enc(E.from_nchw(current), context)
-        return self.Post_process(current, E.to_nchw_f32(weight), E.to_nchw_f32(off16))
+        head = enc.head(E.from_nchw(current), context)
+        return E.propagate_head(current, head, self.Post_process.w, self.Post_process.b, 1.0)
 
     def _keep_input(self, out, d_clear):
         """preserve_input blend (LRRU.py:447-450): valid input pixels overwrite the estimate."""

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("JSPSR_LAB_LIB") or os.path.join(_HERE, "lib", "libjspsr_hip.so")  # JSPSR_LAB_LIB: kernel-lab builds only
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lock = threading.Lock()
 _lib = None
@@ -30,6 +30,9 @@ SIGNATURES = {
     "jspsr_prop_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_prop_backward_f32": (c_i, [c_p] * 4 + [c_i] + [c_p] * 6 + [c_i, c_i, c_i, c_p]),
     "jspsr_prop_backward_fold_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "jspsr_prop_head_forward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
+    "jspsr_prop_head_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "jspsr_prop_head_backward": (c_i, [c_i] + [c_p] * 8 + [c_i, c_i, c_i, c_p]),
     "jspsr_pack_weight": (c_i, [c_i, c_p, c_p] + [c_i] * 6 + [c_p]),
     "jspsr_conv2d_stats_rows": (c_i, [c_i, c_i, c_i]),
     "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p, c_p, c_p, c_i, c_p]),

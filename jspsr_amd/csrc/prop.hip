@@ -7,31 +7,21 @@
 // (108 / 208 with the 16-channel offset layout that drops the all-zero centre pair).
 //
 // Data movement
-//   * a workgroup (256 threads = 4 waves) owns a TH x TW = 16 x 64 pixel tile of one image;
-//     a lane owns 4 consecutive pixels of one row, so every operand plane is read with one
-//     coalesced 16-byte load per lane (a wave instruction covers 4 rows x 256 B);
+//   * a workgroup (256 threads = 4 waves) owns a TH x TW pixel tile of one image (default 8 x 64; JSPSR_PROP_TH /
+//     JSPSR_PROP_TW); a lane owns PX consecutive pixels of one row per pass (default 1: a wave instruction is one
+//     256-byte row segment of one operand plane; 2 / 4 = 8- / 16-byte loads, measured slower: DESIGN.md);
 //   * the DEM tile plus an 8-pixel halo is staged once in LDS (zero outside the raster, which
 //     IS the sampler's border rule); the 9 x 4 corner reads per pixel are LDS reads;
 //   * a tap that lands outside tile+halo (|offset| > ~8 px) falls back to bounds-checked
 //     global reads of the DEM (1 channel: L2 resident);
 //   * tiles are numbered so that an XCD's L2 sees a contiguous run of tiles (halo reuse).
-#include "common.h"
+#include "prop_tile.h"
 
 #include <cstdlib>
 #include <initializer_list>
+#include <type_traits>
 
 namespace {
-
-constexpr int TW = 64;    // tile width  (pixels)
-constexpr int HALO = 8;   // LDS halo on every side
-constexpr int LW = TW + 2 * HALO;  // 80
-constexpr int NT = 256;   // threads per workgroup
-constexpr int NRED = 10;  // grad_wk[9] + grad_b0
-
-struct Geom {
-  int B, H, W, tiles_x, tiles_y, nblk, th;
-  int dem_vec4;  // DEM rows may be staged with 16-byte loads (W % 4 == 0 and a 16-byte aligned base)
-};
 
 // PX consecutive pixels of one plane per lane: PX*4-byte loads when the row pitch and the
 // pointers allow it (VEC), otherwise predicated scalar accesses.
@@ -77,79 +67,6 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const Vec<PX>& r, int
   }
 }
 
-// Stage the DEM tile + halo of image `img` into LDS; zero outside the raster.
-template <int LH>
-__device__ __forceinline__ void stage_dem(float* __restrict__ lds, const float* __restrict__ img,
-                                          int ty0, int tx0, int H, int W, const bool VEC) {
-  for (int i = threadIdx.x; i < LH * (LW / 4); i += NT) {
-    const int r = i / (LW / 4), c = (i % (LW / 4)) * 4;
-    const int gy = ty0 - HALO + r, gx = tx0 - HALO + c;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gy >= 0 && gy < H) {
-      if (VEC) {
-        if (gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(img + (size_t)gy * W + gx);
-      } else {
-        const float* row = img + (size_t)gy * W;
-        if (gx + 0 >= 0 && gx + 0 < W) v.x = row[gx + 0];
-        if (gx + 1 >= 0 && gx + 1 < W) v.y = row[gx + 1];
-        if (gx + 2 >= 0 && gx + 2 < W) v.z = row[gx + 2];
-        if (gx + 3 >= 0 && gx + 3 < W) v.w = row[gx + 3];
-      }
-    }
-    *reinterpret_cast<float4*>(lds + r * LW + c) = v;
-  }
-}
-
-struct Corners {
-  float v00, v01, v10, v11, ly, lx;
-};
-
-// The four bilinear corners of position (py,px); out-of-raster corners are 0
-// (torchvision bilinear_interpolate / get_coordinate_weight corner rule).
-template <int LH>
-__device__ __forceinline__ Corners corners(const float* __restrict__ lds,
-                                           const float* __restrict__ img, int H, int W,
-                                           int ly0, int lx0, float py, float px) {
-  Corners c;
-  const float fy = floorf(py), fx = floorf(px);
-  c.ly = py - fy;
-  c.lx = px - fx;
-  c.v00 = c.v01 = c.v10 = c.v11 = 0.f;
-  // NaN-safe "can any corner be inside the raster" test; also keeps the int casts defined.
-  const bool near = (py > -2.f) && (py < (float)(H + 1)) && (px > -2.f) && (px < (float)(W + 1));
-  if (near) {
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int ry = y0 - ly0, rx = x0 - lx0;
-    if ((unsigned)ry < (unsigned)(LH - 1) && (unsigned)rx < (unsigned)(LW - 1)) {
-      const float* p = lds + ry * LW + rx;
-      c.v00 = p[0];
-      c.v01 = p[1];
-      c.v10 = p[LW];
-      c.v11 = p[LW + 1];
-    } else {
-      const bool y0ok = (unsigned)y0 < (unsigned)H, y1ok = (unsigned)(y0 + 1) < (unsigned)H;
-      const bool x0ok = (unsigned)x0 < (unsigned)W, x1ok = (unsigned)(x0 + 1) < (unsigned)W;
-      const float* p = img + (ptrdiff_t)y0 * W + x0;
-      if (y0ok && x0ok) c.v00 = p[0];
-      if (y0ok && x1ok) c.v01 = p[1];
-      if (y1ok && x0ok) c.v10 = p[W];
-      if (y1ok && x1ok) c.v11 = p[W + 1];
-    }
-  } else {
-    c.ly = c.lx = 0.f;  // keep inf/nan coordinates out of the arithmetic: the tap contributes 0
-  }
-  return c;
-}
-
-__device__ __forceinline__ void tile_coords(const Geom& g, int& b, int& ty0, int& tx0) {
-  const int t = jspsr::xcd_contiguous(blockIdx.x, g.nblk);
-  const int per_img = g.tiles_x * g.tiles_y;
-  b = t / per_img;
-  const int r = t - b * per_img;
-  ty0 = (r / g.tiles_x) * g.th;
-  tx0 = (r % g.tiles_x) * TW;
-}
-
 // offset channel of (tap k, component c) in the OC-channel layout
 template <int OC>
 __device__ __forceinline__ constexpr int och(int k, int c) {
@@ -159,14 +76,14 @@ __device__ __forceinline__ constexpr int och(int k, int c) {
 // Lane -> pixel map: a row of the tile is TW/PX lanes wide; a workgroup pass covers
 // RPP = NT*PX/TW rows and the tile's TH rows take TH/RPP passes (not unrolled: it bounds the
 // live registers to one pass; occupancy, not unrolling, hides the HBM latency).
-template <int OC, int PX, bool VEC, int TH>
+template <int OC, int PX, bool VEC, int TH, int TW>
 __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ dem,
                                                      const float* __restrict__ weight,
                                                      const float* __restrict__ offset,
                                                      const float* __restrict__ wk,
                                                      const float* __restrict__ b0, float scale,
                                                      float* __restrict__ out, Geom g) {
-  constexpr int LH = TH + 2 * HALO;
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float lds[LH * LW];
   constexpr int LPR = TW / PX;       // lanes per tile row
   constexpr int RPP = NT / LPR;      // rows per pass
@@ -175,7 +92,7 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
   const int H = g.H, W = g.W;
   const size_t P = (size_t)H * W;
   const float* img = dem + (size_t)b * P;
-  stage_dem<LH>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
+  stage_dem<LH, LW>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
@@ -215,7 +132,7 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
       for (int k = 0; k < 9; ++k) {
         const float py = (float)(y - 1 + k / 3) + oy[k].v[j];
         const float px = (float)(x + j - 1 + k % 3) + ox[k].v[j];
-        const Corners c = corners<LH>(lds, img, H, W, ly0, lx0, py, px);
+        const Corners c = corners<LH, LW>(lds, img, H, W, ly0, lx0, py, px);
         const float hy = 1.f - c.ly, hx = 1.f - c.lx;
         const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
         acc += wreg[k] * (a[k].v[j] - mean) * S;
@@ -226,13 +143,85 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
   }
 }
 
-template <int OC, int PX, bool VEC, int TH>
+// Forward, prefetching form (one pixel per lane): the operand loads of ALL passes of the tile are issued before the DEM
+// tile is staged, so the staging round trip, the barrier and the operand round trips overlap instead of following one
+// another (3 dependent HBM round trips per workgroup -> 1), and every lane has NPASS x 26 loads in flight.
+template <int OC, int TH, int TW>
+__global__ __launch_bounds__(NT) void prop_fwd_pf_kernel(const float* __restrict__ dem,
+                                                        const float* __restrict__ weight,
+                                                        const float* __restrict__ offset,
+                                                        const float* __restrict__ wk,
+                                                        const float* __restrict__ b0, float scale,
+                                                        float* __restrict__ out, Geom g) {
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+  __shared__ __attribute__((aligned(16))) float lds[LH * LW];
+  constexpr int RPP = NT / TW;       // rows per pass
+  constexpr int NPASS = TH / RPP;
+  static_assert(TH % RPP == 0 && NPASS >= 1 && NPASS <= 4, "tile shape");
+  int b, ty0, tx0;
+  tile_coords(g, b, ty0, tx0);
+  const int H = g.H, W = g.W;
+  const size_t P = (size_t)H * W;
+  const float* img = dem + (size_t)b * P;
+  const int x = tx0 + (int)(threadIdx.x % TW);
+  const int yl = ty0 + (int)(threadIdx.x / TW);
+  float a[NPASS][9], oy[NPASS][9], ox[NPASS][9], dc[NPASS];
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int y = yl + p * RPP;
+    const bool ok = x < W && y < H;
+    const size_t pix = ok ? (size_t)y * W + x : 0;
+    const float* wp = weight + (size_t)b * 9 * P + pix;
+    const float* op = offset + (size_t)b * OC * P + pix;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      a[p][k] = ok ? wp[k * P] : 0.f;
+      if (OC == 18 || k != 4) {
+        oy[p][k] = ok ? op[(size_t)och<OC>(k, 0) * P] : 0.f;
+        ox[p][k] = ok ? op[(size_t)och<OC>(k, 1) * P] : 0.f;
+      } else {
+        oy[p][k] = ox[p][k] = 0.f;
+      }
+    }
+    dc[p] = ok ? img[pix] : 0.f;
+  }
+  stage_dem<LH, LW>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
+  float wreg[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
+  const float bias = b0[0];
+  __syncthreads();
+  const int ly0 = ty0 - HALO, lx0 = tx0 - HALO;
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int y = yl + p * RPP;
+    if (x < W && y < H) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s += a[p][k];
+      const float mean = s / 9.f;
+      float acc = bias;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float py = (float)(y - 1 + k / 3) + oy[p][k];
+        const float px = (float)(x - 1 + k % 3) + ox[p][k];
+        const Corners c = corners<LH, LW>(lds, img, H, W, ly0, lx0, py, px);
+        const float hy = 1.f - c.ly, hx = 1.f - c.lx;
+        const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
+        acc += wreg[k] * (a[p][k] - mean) * S;
+      }
+      out[(size_t)b * P + (size_t)y * W + x] = acc + scale * dc[p];
+    }
+  }
+}
+
+template <int OC, int PX, bool VEC, int TH, int TW>
 __global__ __launch_bounds__(NT) void prop_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ dem,
     const float* __restrict__ weight, const float* __restrict__ offset,
     const float* __restrict__ wk, float* __restrict__ gweight, float* __restrict__ goffset,
     float* __restrict__ partial, Geom g) {
-  constexpr int LH = TH + 2 * HALO;
+  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float lds[LH * LW];
   __shared__ float red[NT / 64][NRED];
   constexpr int LPR = TW / PX;
@@ -242,7 +231,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
   const int H = g.H, W = g.W;
   const size_t P = (size_t)H * W;
   const float* img = dem + (size_t)b * P;
-  stage_dem<LH>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
+  stage_dem<LH, LW>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
@@ -289,7 +278,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
         for (int k = 0; k < 9; ++k) {
           const float py = (float)(y - 1 + k / 3) + oy[k].v[j];
           const float px = (float)(x + j - 1 + k % 3) + ox[k].v[j];
-          const Corners c = corners<LH>(lds, img, H, W, ly0, lx0, py, px);
+          const Corners c = corners<LH, LW>(lds, img, H, W, ly0, lx0, py, px);
           const float hy = 1.f - c.ly, hx = 1.f - c.lx;
           const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
           const float dSdy = hx * (c.v10 - c.v00) + c.lx * (c.v11 - c.v01);
@@ -336,33 +325,23 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
   }
 }
 
-// One workgroup per parameter gradient (9 tap weights + bias): 256 lanes stride over the partial
-// rows in fp64, then a fixed-order tree -> bit-reproducible run to run.
-__global__ __launch_bounds__(256) void prop_bwd_finalize(const float* __restrict__ partial,
-                                                        int nblk, float* __restrict__ gwk,
-                                                        float* __restrict__ gb0) {
-  __shared__ double red[4];
-  const int col = blockIdx.x;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partial[(size_t)i * NRED + col];
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double t = (red[0] + red[1]) + (red[2] + red[3]);
-    if (col < 9) gwk[col] = (float)t; else gb0[0] = (float)t;
-  }
+// Tile shape.  Defaults are what measured best on MI355X; JSPSR_PROP_TH x JSPSR_PROP_TW select one of the
+// built shapes for A/B measurements: 64-wide tiles 4 / 8 / 16 rows tall, 128 x {4, 8}, 256 x {2, 4, 8}.
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
-// Tile height.  Tunable through JSPSR_PROP_TH (4, 8 or 16); 8 measured best on MI355X.
-int prop_th() {
-  static const int th = [] {
-    const char* e = getenv("JSPSR_PROP_TH");
-    const int v = e ? atoi(e) : 8;
-    return (v == 4 || v == 8 || v == 16) ? v : 8;
+void tile_shape(int& th, int& tw) {
+  static const int tw_ = [] { const int v = env_int("JSPSR_PROP_TW", 64); return (v == 64 || v == 128 || v == 256) ? v : 64; }();
+  static const int th_ = [] {
+    const int v = env_int("JSPSR_PROP_TH", 8);
+    if (tw_ == 64) return (v == 4 || v == 8 || v == 16) ? v : 8;
+    if (tw_ == 128) return (v == 4 || v == 8) ? v : 8;
+    return (v == 2 || v == 4 || v == 8) ? v : 4;
   }();
-  return th;
+  th = th_;
+  tw = tw_;
 }
 
 int make_geom(int B, int H, int W, Geom& g) {
@@ -370,8 +349,8 @@ int make_geom(int B, int H, int W, Geom& g) {
   g.B = B;
   g.H = H;
   g.W = W;
-  g.tiles_x = (W + TW - 1) / TW;
-  g.th = prop_th();
+  tile_shape(g.th, g.tw);
+  g.tiles_x = (W + g.tw - 1) / g.tw;
   g.tiles_y = (H + g.th - 1) / g.th;
   const long long n = (long long)B * g.tiles_x * g.tiles_y;
   if (n > 0x7fffffffLL || (long long)B * 18 * H * W > (1LL << 40))
@@ -380,12 +359,11 @@ int make_geom(int B, int H, int W, Geom& g) {
   return JSPSR_OK;
 }
 
-// Pixels per lane.  Tunable for experiments through JSPSR_PROP_PX (1, 2 or 4); the default is
+// Pixels per lane.  Tunable for experiments through JSPSR_PROP_PX (1, 2 or 4; 64-wide tiles only); the default is
 // what measured fastest on MI355X.
 int prop_px() {
   static const int px = [] {
-    const char* e = getenv("JSPSR_PROP_PX");
-    const int v = e ? atoi(e) : 1;
+    const int v = env_int("JSPSR_PROP_PX", 1);
     return (v == 1 || v == 2 || v == 4) ? v : 1;
   }();
   return px;
@@ -396,6 +374,37 @@ bool can_vec(int W, int px, std::initializer_list<const void*> ptrs) {
   for (const void* p : ptrs)
     if (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(4 * px - 1)) return false;
   return true;
+}
+
+// Calls f(std::integral_constant...) for the built (OC, PX, VEC, TH, TW) combination matching the run-time choice.
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <typename F>
+void by_shape(int oc, int px, bool vec, int th, int tw, F&& f) {
+  auto with_tile = [&](auto OCc, auto PXc, auto VECc) {
+    if (tw == 64) {
+      if (th == 16) f(OCc, PXc, VECc, IC<16>{}, IC<64>{});
+      else if (th == 4) f(OCc, PXc, VECc, IC<4>{}, IC<64>{});
+      else f(OCc, PXc, VECc, IC<8>{}, IC<64>{});
+    }
+  };
+  auto wide = [&](auto OCc) {          // wide tiles: one pixel per lane only
+    if (tw == 128) {
+      if (th == 4) f(OCc, IC<1>{}, IC<1>{}, IC<4>{}, IC<128>{});
+      else f(OCc, IC<1>{}, IC<1>{}, IC<8>{}, IC<128>{});
+    } else {
+      if (th == 2) f(OCc, IC<1>{}, IC<1>{}, IC<2>{}, IC<256>{});
+      else if (th == 8) f(OCc, IC<1>{}, IC<1>{}, IC<8>{}, IC<256>{});
+      else f(OCc, IC<1>{}, IC<1>{}, IC<4>{}, IC<256>{});
+    }
+  };
+  auto with_px = [&](auto OCc) {
+    if (tw != 64) { wide(OCc); return; }
+    if (px == 1) with_tile(OCc, IC<1>{}, IC<1>{});
+    else if (px == 2) { if (vec) with_tile(OCc, IC<2>{}, IC<1>{}); else with_tile(OCc, IC<2>{}, IC<0>{}); }
+    else { if (vec) with_tile(OCc, IC<4>{}, IC<1>{}); else with_tile(OCc, IC<4>{}, IC<0>{}); }
+  };
+  if (oc == 18) with_px(IC<18>{}); else with_px(IC<16>{});
 }
 
 }  // namespace
@@ -411,18 +420,25 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
   if (int e = make_geom(B, H, W, g)) return e;
   for (const void* p : {(const void*)dem, (const void*)weight, (const void*)offset, (const void*)out})
     if (!jspsr::aligned4(p)) return jspsr::fail(JSPSR_EALIGN, "prop_forward: pointer not 4-byte aligned");
-  const int px = prop_px();
+  const int px = g.tw == 64 ? prop_px() : 1;
   const bool vec = can_vec(W, px, {dem, weight, offset, out});
   g.dem_vec4 = can_vec(W, 4, {dem});
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(g.nblk), block(NT);
-#define LAUNCH_TH(OC, PX, V, T) hipLaunchKernelGGL((prop_fwd_kernel<OC, PX, V, T>), grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g)
-#define LAUNCH(OC, PX, V) do { if (g.th == 16) LAUNCH_TH(OC, PX, V, 16); else if (g.th == 8) LAUNCH_TH(OC, PX, V, 8); else LAUNCH_TH(OC, PX, V, 4); } while (0)
-#define BY_VEC(OC, PX) do { if (vec) LAUNCH(OC, PX, true); else LAUNCH(OC, PX, false); } while (0)
-#define BY_PX(OC) do { if (px == 1) LAUNCH(OC, 1, true); else if (px == 2) BY_VEC(OC, 2); else BY_VEC(OC, 4); } while (0)
-  if (offset_channels == 18) BY_PX(18); else BY_PX(16);
-#undef LAUNCH
-#undef LAUNCH_TH
+  static const int pf = env_int("JSPSR_PROP_PF", 0);
+  if (pf && px == 1 && g.tw * g.th <= 4 * NT) {
+    by_shape(offset_channels, 1, true, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
+      if constexpr (decltype(THc)::value * decltype(TWc)::value <= 4 * NT && decltype(PXc)::value == 1)
+        hipLaunchKernelGGL((prop_fwd_pf_kernel<decltype(OCc)::value, decltype(THc)::value, decltype(TWc)::value>),
+                           grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g);
+    });
+    return jspsr::check_launch("prop_forward");
+  }
+  by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
+    hipLaunchKernelGGL((prop_fwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
+                                        decltype(THc)::value, decltype(TWc)::value>),
+                       grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g);
+  });
   return jspsr::check_launch("prop_forward");
 }
 
@@ -447,19 +463,17 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
                         (const void*)grad_weight, (const void*)grad_offset})
     if (!jspsr::aligned4(p)) return jspsr::fail(JSPSR_EALIGN, "prop_backward: pointer not 4-byte aligned");
   if (!jspsr::aligned16(workspace)) return jspsr::fail(JSPSR_EALIGN, "prop_backward: workspace not 16-byte aligned");
-  const int px = prop_px();
+  const int px = g.tw == 64 ? prop_px() : 1;
   const bool vec = can_vec(W, px, {grad_out, dem, weight, offset, grad_weight, grad_offset});
   g.dem_vec4 = can_vec(W, 4, {dem});
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   dim3 grid(g.nblk), block(NT);
-#define LAUNCH_TH(OC, PX, V, T) hipLaunchKernelGGL((prop_bwd_kernel<OC, PX, V, T>), grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g)
-#define LAUNCH(OC, PX, V) do { if (g.th == 16) LAUNCH_TH(OC, PX, V, 16); else if (g.th == 8) LAUNCH_TH(OC, PX, V, 8); else LAUNCH_TH(OC, PX, V, 4); } while (0)
-  if (offset_channels == 18) BY_PX(18); else BY_PX(16);
-#undef LAUNCH
-#undef LAUNCH_TH
-#undef BY_VEC
-#undef BY_PX
+  by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
+    hipLaunchKernelGGL((prop_bwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
+                                        decltype(THc)::value, decltype(TWc)::value>),
+                       grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g);
+  });
   if (int e = jspsr::check_launch("prop_backward")) return e;
   if (!grad_wk) return JSPSR_OK;   // partial rows only: the caller folds them later (jspsr_prop_backward_fold_f32)
   hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, g.nblk, grad_wk, grad_b0);

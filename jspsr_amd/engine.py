@@ -153,6 +153,11 @@ def channel_gate(x, w1, w2):
     return ops.channel_gate(x, w1, w2)
 
 
+def propagate_head(dem, head, w, b, scale=1.0):
+    """K1h: sigmoid + propagation straight from the merged 1x1 head's NHWC output (ops.propagate_head)."""
+    return ops.propagate_head(dem.contiguous(), head, w, b, scale)
+
+
 def cat(tensors):
     return torch.cat(tuple(tensors), 3)
 

@@ -11,6 +11,7 @@ import os
 import torch
 
 from . import _lib
+from . import kernels as K
 
 
 def _stream() -> int:
@@ -103,14 +104,98 @@ def propagate(dem, weight, offset, w, b, scale: float = 1.0):
     (B,16,H,W) without the all-zero centre pair; w (1,1,3,3); b (1,).  No gradient flows to dem
     (the reference detaches it: models/JSPSR.py:372).
     """
+    if dem.requires_grad:
+        raise RuntimeError("propagate: dem requires grad, but this operator produces no gradient with respect to the DEM "
+                           "(every reference caller detaches it); use propagate_steps for chains that need it")
     return _Propagate.apply(dem, weight, offset, w, b, scale)
+
+
+# ---- K1h: propagation fed straight from the merged 1x1 head's NHWC output ---------------------------------------------
+HEAD_CHANNELS = 32
+
+
+def head_rows():
+    """Row order of the merged head convolution ("tap-major", include/jspsr_hip.h K1h): for the 8 learned taps t
+    (k = t < 4 ? t : t + 1): [affinity row k, offset row 2t (dy), offset row 2t+1 (dx), extra], extra = the centre
+    tap's affinity row (k = 4) for t == 0, a zero row otherwise.  Returns (kind, index) pairs: ("w", k), ("o", j),
+    ("z", 0)."""
+    rows = []
+    for t in range(8):
+        k = t if t < 4 else t + 1
+        rows += [("w", k), ("o", 2 * t), ("o", 2 * t + 1), ("w", 4) if t == 0 else ("z", 0)]
+    return rows
+
+
+def merge_heads(w_weight, b_weight, w_offset, b_offset):
+    """(9,C,1,1)/(9,) affinity head + (16,C,1,1)/(16,) offset head -> (32,C,1,1)/(32,) tap-major merged head
+    (differentiable: the gradients of the merged rows flow back to the two reference-named parameters)."""
+    zw, zb = w_weight.new_zeros((1,) + tuple(w_weight.shape[1:])), b_weight.new_zeros(1)
+    pick_w = {"w": w_weight, "o": w_offset, "z": zw}
+    pick_b = {"w": b_weight, "o": b_offset, "z": zb}
+    rows = head_rows()
+    return (torch.cat([pick_w[kind][i:i + 1] for kind, i in rows], 0),
+            torch.cat([pick_b[kind][i:i + 1] for kind, i in rows], 0))
+
+
+def split_head(head):
+    """(B,H,W,32) tap-major head -> (affinity logits (B,H,W,9) in window order, offsets (B,H,W,16)) -- views/gathers
+    for callers that need the reference's two tensors (tests, the halo check of sharded inference)."""
+    h = head.reshape(*head.shape[:3], 8, 4)
+    logits = torch.cat((h[..., :4, 0], h[..., 0:1, 3], h[..., 4:, 0]), -1)
+    return logits, h[..., 1:3].reshape(*head.shape[:3], 16)
+
+
+class _PropagateHead(torch.autograd.Function):
+    """Sigmoid (spn.py:43) + zero centre offset (spn.py:69-73) + PostProcessor.forward (spn.py:99-118) on the merged
+    head's output, one HIP kernel each way (jspsr_prop_head_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx, dem, head, w, b, scale):
+        _need_gpu(dem, w, b)
+        if not head.is_cuda or head.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("propagate_head: head must be a float32 or bfloat16 GPU tensor")
+        B, one, H, W = dem.shape
+        if one != 1 or tuple(head.shape) != (B, H, W, HEAD_CHANNELS):
+            raise ValueError(f"propagate_head: dem {tuple(dem.shape)} against head {tuple(head.shape)} (want (B,H,W,{HEAD_CHANNELS}))")
+        if w.numel() != 9 or b.numel() != 1:
+            raise ValueError("propagate_head: w must have 9 elements and b 1")
+        dem, head, w, b = dem.contiguous(), head.contiguous(), w.contiguous(), b.contiguous()
+        out = torch.empty_like(dem)
+        lib = _lib.load()
+        _lib.check(lib.jspsr_prop_head_forward(K._dt(head), dem.data_ptr(), head.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                               float(scale), out.data_ptr(), B, H, W, _stream()), "jspsr_prop_head_forward")
+        ctx.save_for_backward(dem, head, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dem, head, w = ctx.saved_tensors
+        B, _, H, W = dem.shape
+        grad_out = grad_out.contiguous()
+        ghead = torch.empty_like(head)
+        gw = torch.empty_like(w)
+        gb = torch.empty(1, device=dem.device, dtype=dem.dtype)
+        lib = _lib.load()
+        ws = torch.empty(max(lib.jspsr_prop_head_backward_workspace_bytes(B, H, W), 16), dtype=torch.uint8, device=dem.device)
+        _lib.check(lib.jspsr_prop_head_backward(K._dt(head), grad_out.data_ptr(), dem.data_ptr(), head.data_ptr(),
+                                                w.data_ptr(), ghead.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(),
+                                                B, H, W, _stream()), "jspsr_prop_head_backward")
+        return None, ghead, gw, gb, None
+
+
+def propagate_head(dem, head, w, b, scale: float = 1.0):
+    """out = b + sum_k w_k (a_k - mean a) bilinear(dem, p_k + offset_k) + scale*dem with a = sigmoid(affinity logits),
+    operands in the merged head's tap-major NHWC layout (`merge_heads`).  dem (B,1,H,W) fp32, head (B,H,W,32) fp32 or
+    bf16.  No gradient flows to dem (detached by every caller: models/JSPSR.py:372, LRRU.py:453-496)."""
+    if dem.requires_grad:
+        raise RuntimeError("propagate_head: dem must be detached (no gradient with respect to the DEM is produced)")
+    return _PropagateHead.apply(dem, head, w, b, scale)
 
 
 # =============================================================================================
 # NHWC layer operators: torch.autograd.Function shells around jspsr_amd.kernels (HIP).
 # Tensors are (B, H, W, C) contiguous, fp32 or bf16; parameters stay fp32 masters.
 # =============================================================================================
-from . import kernels as K  # noqa: E402
 
 
 def pad_channels(x: torch.Tensor, mult: int) -> torch.Tensor:

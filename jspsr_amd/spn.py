@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
+from . import ops
 from .blocks import ConvUnit, ResUnit
 
 
@@ -51,6 +52,13 @@ class Generator(nn.Module):
         y = E.conv2d(feature, w_all, b_all)
         return E.sigmoid(y[..., :nw]), y[..., nw:nw + no]
 
+    def head(self, feature):
+        """The two 1x1 heads as ONE 32-channel convolution in the tap-major order K1h reads (ops.merge_heads): affinity
+        LOGITS (the Sigmoid of spn.py:43 is applied inside the propagation kernel, in fp32) and learned offsets."""
+        cw, co = self.conv_weight[0], self.conv_offset.conv[0]
+        w_all, b_all = ops.merge_heads(cw.weight, cw.bias, co.weight, co.bias)
+        return E.conv2d(feature, w_all, b_all)
+
     def forward(self, dem, context):
         """Reference contract: NCHW in, (weight (B,9,H,W), offset (B,18,H,W)) NCHW fp32 out."""
         weight, off16 = self.heads(self.features(E.from_nchw(dem), E.from_nchw(context)))
@@ -79,3 +87,7 @@ class PostProcessor(nn.Module):
     def forward(self, init_dem, weight, offset):
         """offset: (B,18,H,W) torchvision layout, or (B,16,H,W) without the zero centre pair."""
         return E.propagate(init_dem, weight, offset, self.w, self.b, self.scale)
+
+    def from_head(self, init_dem, head):
+        """Inside the models: the merged head's NHWC output (Generator.head) goes straight into the kernel."""
+        return E.propagate_head(init_dem, head, self.w, self.b, self.scale)

@@ -99,3 +99,22 @@ def test_two_ranks_one_card_full_step(tmp_path):
     for i, (a, b, got) in enumerate(zip(ref[0], ref[1], g0)):
         want = (a + b) / 2
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-9 + 1e-6 * want.abs().max().item()), i
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without torch.distributed.run must start its own two ranks (child processes created
+    before anything touches the GPU) and print ONE JSON line for n_gpus 2.  One-GPU rehearsal: both ranks on cuda:0
+    over gloo (JSPSR_BENCH_REHEARSAL=1); on a real node the same code path runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["JSPSR_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "1", "--no-roofline"], env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["global_tiles"] == 2

@@ -218,3 +218,102 @@ def test_backward_split_into_stream_and_fold():
         outs.append((gw_, go_, gk, gb))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# ---- K1h: the head-fed entry (jspsr_prop_head_forward / _backward) -------------------------------------------------
+def _head_case(B, H, W, dtype, seed, sigma=2.0):
+    """Random tap-major head tensor (stored in `dtype`) + the planar operands the reference would see for it."""
+    from jspsr_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    dem = torch.rand(B, 1, H, W, generator=g, dtype=torch.float64)
+    head = torch.randn(B, H, W, 32, generator=g, dtype=torch.float64)
+    h5 = head.view(B, H, W, 8, 4)
+    h5[..., 1:3] *= sigma
+    h5[0, : min(4, H), : min(6, W), :, 1:3] = torch.randint(-3, 4, (min(4, H), min(6, W), 8, 2), generator=g).double()   # integer taps
+    h5[0, min(4, H - 1):min(7, H), : min(6, W), :, 1:3] *= 20.0                                                       # far out of the tile / raster
+    head = head.to(dtype)                       # what the head convolution would have stored
+    logits, off16 = ops.split_head(head.double())
+    weight = torch.sigmoid(logits).permute(0, 3, 1, 2).contiguous()
+    off16 = off16.permute(0, 3, 1, 2).contiguous()
+    zero = torch.zeros(B, 2, H, W, dtype=torch.float64)
+    offset = torch.cat((off16[:, :8], zero, off16[:, 8:]), 1)
+    w = 1 + 0.3 * torch.randn(1, 1, 3, 3, generator=g, dtype=torch.float64)
+    b = 0.1 * torch.randn(1, generator=g, dtype=torch.float64)
+    gout = torch.randn(B, 1, H, W, generator=g, dtype=torch.float64)
+    return dem, head, weight, offset, w, b, gout
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 13, 70), (3, 8, 64), (1, 1, 1), (2, 40, 129)])
+def test_head_entry_matches_oracle(B, H, W, dtype):
+    """Forward and backward of the head-fed kernel against the fp64 oracle evaluated on the SAME stored head values
+    (sigmoid and zero centre offset applied by the oracle as the reference's Generator does, spn.py:43,69-73).  Ragged
+    sizes (W % 8 != 0, H < tile), integer taps and far-out taps included.  fp32: 5e-6 abs on the output, 2e-5 relative
+    on the gradients; bf16: same bound on the output (the arithmetic is fp32 either way), gradient tensor compared
+    after ITS storage rounding (2^-8 relative per element)."""
+    from jspsr_amd import ops
+    dem, head, weight, offset, w, b, gout = _head_case(B, H, W, dtype, seed=B * 100 + H + W)
+    head_d = head.cuda().requires_grad_()
+    w_d, b_d = w.float().cuda().requires_grad_(), b.float().cuda().requires_grad_()
+    out = ops.propagate_head(dem.float().cuda(), head_d, w_d, b_d, 1.0)
+    out.backward(gout.float().cuda())
+    # oracle: autograd through sigmoid / split on the stored values, in fp64
+    head64 = head.double().requires_grad_()
+    logits, off16 = ops.split_head(head64)
+    wt = torch.sigmoid(logits).permute(0, 3, 1, 2)
+    o16 = off16.permute(0, 3, 1, 2)
+    off18 = torch.cat((o16[:, :8], torch.zeros(B, 2, H, W, dtype=torch.float64), o16[:, 8:]), 1)
+    w64, b64 = w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = R.propagate(dem, wt, off18, w64, b64)
+    ref.backward(gout)
+    # the float32 operand of the kernel is dem.float(): evaluate the tolerance against the fp64 oracle on fp64 dem
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 5e-6
+    gh, gr = head_d.grad.cpu().double(), head64.grad
+    # d/d(offset) jumps at integer sampling positions and where a tap crosses the raster border: compare off that set
+    h5 = head.double().view(B, H, W, 8, 4)
+    smooth = (h5[..., 1:3] != h5[..., 1:3].round()).all(-1, keepdim=True).expand(B, H, W, 8, 4).reshape(B, H, W, 32).double()
+    if dtype == torch.float32:
+        assert ((gh - gr) * smooth).abs().max().item() < 2e-5 * gr.abs().max().item() + 1e-7
+    else:
+        assert ((gh - gr) * smooth).abs().max().item() < 2.0 ** -8 * gr.abs().max().item() + 1e-7
+        assert (((gh - gr) * smooth).norm() / gr.norm()).item() < 2.0 ** -8
+    pad = gh.view(B, H, W, 8, 4)[..., 1:, 3]
+    assert pad.abs().max().item() == 0.0                               # unused channels carry exact zeros
+    assert abs(w_d.grad.cpu().double() - w64.grad).max().item() < 1e-5 * w64.grad.abs().max().item() + 1e-6
+    assert abs(b_d.grad.cpu().double() - b64.grad).max().item() < 1e-5 * abs(b64.grad).max().item() + 1e-6
+
+
+def test_head_entry_equals_planar_entry_on_the_same_numbers():
+    """The two ABI entries are the same operator on two layouts: fp32 head -> (sigmoid, split) -> planar kernel."""
+    from jspsr_amd import ops
+    dem, head, weight, offset, w, b, gout = _head_case(2, 32, 96, torch.float32, seed=77)
+    out_h = ops.propagate_head(dem.float().cuda(), head.cuda(), w.float().cuda(), b.float().cuda(), 1.0)
+    out_p = ops.propagate(dem.float().cuda(), weight.float().cuda(), offset.float().cuda(), w.float().cuda(), b.float().cuda(), 1.0)
+    assert (out_h - out_p).abs().max().item() < 2e-6
+
+
+def test_head_entry_full_size_properties():
+    """BASELINE size (8 x 512 x 512), both dtypes: equal affinity logits => out = b + dem exactly up to rounding
+    (zero-sum affinities); linearity in the upstream gradient; finite everywhere."""
+    from jspsr_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, H, W = 8, 512, 512
+    dem = torch.rand(B, 1, H, W, device="cuda", generator=g)
+    w = (1 + 0.2 * torch.randn(1, 1, 3, 3, device="cuda", generator=g))
+    b = torch.full((1,), 0.125, device="cuda")
+    for dtype in (torch.float32, torch.bfloat16):
+        head = torch.randn(B, H, W, 32, device="cuda", generator=g)
+        h5 = head.view(B, H, W, 8, 4)
+        h5[..., 0] = 0.3
+        h5[..., 0, 3] = 0.3                      # all nine logits equal
+        w1 = torch.ones(1, 1, 3, 3, device="cuda")
+        out = ops.propagate_head(dem, head.to(dtype), w1, b, 1.0)
+        assert (out - (dem + 0.125)).abs().max().item() < 2e-6
+        head2 = (1.5 * torch.randn(B, H, W, 32, device="cuda", generator=g)).to(dtype).requires_grad_()
+        o = ops.propagate_head(dem, head2, w, b, 1.0)
+        g1 = torch.randn(B, 1, H, W, device="cuda", generator=g)
+        (ga,) = torch.autograd.grad(o, head2, g1, retain_graph=True)
+        (gb,) = torch.autograd.grad(o, head2, 2 * g1)
+        assert torch.isfinite(o).all() and torch.isfinite(ga).all()
+        tol = 1e-6 if dtype == torch.float32 else 2.0 ** -7
+        assert ((gb.float() - 2 * ga.float()).abs().max() <= tol * ga.float().abs().max()).item()

@@ -79,3 +79,52 @@ def test_flat_adamw_second_lr_group_and_schedule():
         assert sch.get_last_lr() == rsch.get_last_lr()
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_flat_adamw_checkpoint_round_trip_is_bit_exact(tmp_path):
+    """The reference saves optimizer.state_dict() with every improved model (main.py:246-252) and restores it on resume
+    (utils/utils.py:394): save after 3 steps -> torch.save / torch.load -> fresh model + optimizer -> 3 more steps
+    must equal 6 uninterrupted steps bit for bit, with the parameter / gradient aliases into the flat buffers intact."""
+    from jspsr_amd.ddp import GradReducer
+    from jspsr_amd.optim import FlatAdamW, WarmupStepLR
+    torch.manual_seed(2)
+    mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.ReLU(), torch.nn.Conv2d(8, 5, 1)).cuda()
+    x = torch.randn(4, 3, 9, 9, device="cuda")
+
+    def make(net):
+        red = GradReducer(net.parameters())
+        opt = FlatAdamW(red, lr=1e-3, weight_decay=1e-6, lr_overrides={p: 3e-4 for p in net[2].parameters()})
+        return red, opt, WarmupStepLR(opt, warmup_epoch=2, step_size=2, gamma=0.5)
+
+    def steps(net, red, opt, sch, n):
+        for _ in range(n):
+            opt.zero_grad()
+            net(x).square().mean().backward()
+            red.finish()
+            opt.step()
+            sch.step()
+
+    a = mk()
+    start = {k: v.clone() for k, v in a.state_dict().items()}
+    ra, oa, sa = make(a)
+    steps(a, ra, oa, sa, 6)
+    b = mk()
+    b.load_state_dict(start)
+    rb, ob, sb = make(b)
+    steps(b, rb, ob, sb, 3)
+    path = tmp_path / "ckpt.pt"
+    torch.save({"optimizer": ob.state_dict(), "state_dict": b.state_dict(), "scheduler": sb.state_dict()}, path)
+    ck = torch.load(path)
+    c = mk()
+    rc, oc, sc = make(c)
+    c.load_state_dict(ck["state_dict"])
+    oc.load_state_dict(ck["optimizer"])
+    sc.load_state_dict(ck["scheduler"])
+    for p in c.parameters():                      # still views of the optimizer's flat buffers
+        assert oc.flat_p.data_ptr() <= p.data_ptr() < oc.flat_p.data_ptr() + oc.flat_p.numel() * 4
+        assert rc.flat.data_ptr() <= p.grad.data_ptr() < rc.flat.data_ptr() + rc.flat.numel() * 4
+    steps(c, rc, oc, sc, 3)
+    assert oc.steps == oa.steps == 6 and sc.get_last_lr() == sa.get_last_lr()
+    for pa, pc in zip(a.parameters(), c.parameters()):
+        assert torch.equal(pa, pc)
+    assert torch.equal(oa.exp_avg, oc.exp_avg) and torch.equal(oa.exp_avg_sq, oc.exp_avg_sq)

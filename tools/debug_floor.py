@@ -1,0 +1,35 @@
+"""Per-parameter gradient error of the HIP model vs the fp64 oracle, beside the oracle's measured noise floor
+(tests/fixtures.py::gradient_noise_floor) -- debug aid for tests/test_model_gpu.py."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from jspsr_amd.JSPSR import Model
+from oracle import jspsr_ref as R
+from tests import fixtures as Fx
+
+name = sys.argv[1]
+ic = Fx.MSK if "msk" in name else Fx.IMG
+z = Fx.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"), name)
+sd, inputs, gt = Fx.regen_jspsr(z, ic)
+m = Model(dict(ic, COP30=1), num_feature=int(z["nf"]))
+m.load_state_dict(Fx.as_f32(sd))
+m = m.cuda().train()
+if len(sys.argv) > 2 and sys.argv[2] == "nostreams":
+    from jspsr_amd import ops
+    m.branch_streams = False
+    ops.wgrad_async = False
+probe = R.probe_gradient(z["pred"].shape, int(z["seed"]) + 2)
+pred = m(*[t.float().cuda() for t in inputs])
+(pred * probe.float().cuda()).mean().backward()
+fwd = lambda sd_, inp: R.jspsr_forward(sd_, inp, True)
+_, g_ref = Fx.oracle_gradients(fwd, sd, inputs, probe)
+dev = (pred.detach().cpu().double() - torch.from_numpy(z["pred"])).abs().max().item()
+floor = Fx.gradient_noise_floor(fwd, sd, inputs, probe, g_ref, forward_dev=dev, pred_ref=torch.from_numpy(z["pred"]))
+_, g32 = Fx.oracle_gradients(fwd, sd, inputs, probe, torch.float32)
+print("pred err", (pred.detach().cpu().double() - torch.from_numpy(z["pred"])).abs().max().item())
+for k, p in m.named_parameters():
+    e = Fx.rel(p.grad, g_ref[k])
+    e32 = Fx.rel(g32[k], g_ref[k])
+    r = e / (2 * floor[k][1] + 1e-5)
+    print(f"{k:50s} hip {e:.2e} cpu32 {e32:.2e} floor {floor[k][1]:.2e} ratio {r:7.2f}{' <<<<' if r > 1 else ''}")
