@@ -73,6 +73,28 @@ int jspsr_prop_backward_f32(const float* grad_out, const float* dem, const float
 int jspsr_prop_backward_fold_f32(const void* workspace, int B, int H, int W, float* grad_wk, float* grad_b0,
                                  jspsr_stream_t stream);
 
+/* ---- K1s: one propagation step in its general form, for chains of steps ------------------------------------------
+ * Replaces NLSPN._propagate_once, models/components/nlspn.py:177-187, called prop_time times on its own output
+ * (nlspn.py:226-233) with affinities normalised once outside the loop (nlspn.py:158-173) -- and, with normalize != 0,
+ * is the same operator as jspsr_prop_forward_f32 / jspsr_prop_backward_f32 plus the gradient they do not produce.
+ *   normalize == 0:  out = b0 + sum_k wk[k] weight_k S_k + scale * dem      (affinities taken as they are)
+ *   normalize != 0:  out = b0 + sum_k wk[k] (weight_k - mean_k weight) S_k + scale * dem      (spn.py:99-118)
+ * Operand layout as for jspsr_prop_forward_f32.  out must not alias dem.
+ * Backward: grad_weight / grad_offset are overwritten, or ADDED to when accumulate != 0 (the affinities and offsets
+ * of an N-step chain are shared by all steps: their gradients sum over the steps).  grad_dem (may be NULL): the
+ * gradient with respect to dem is ADDED into it (bilinear scatter + scale * grad_out; the caller zero-fills it or
+ * lets it carry another contribution); it uses float atomics, so its last bits depend on the execution order.
+ * grad_wk / grad_b0: both NULL (partial rows stay in the workspace) or both valid (overwritten).
+ * workspace: jspsr_prop_step_backward_workspace_bytes() bytes, 16-byte aligned. */
+int jspsr_prop_step_forward_f32(const float* dem, const float* weight, const float* offset, int offset_channels,
+                                const float* wk, const float* b0, float scale, int normalize, float* out,
+                                int B, int H, int W, jspsr_stream_t stream);
+size_t jspsr_prop_step_backward_workspace_bytes(int B, int H, int W);
+int jspsr_prop_step_backward_f32(const float* grad_out, const float* dem, const float* weight, const float* offset,
+                                 int offset_channels, const float* wk, float scale, int normalize, int accumulate,
+                                 float* grad_weight, float* grad_offset, float* grad_dem, float* grad_wk,
+                                 float* grad_b0, void* workspace, int B, int H, int W, jspsr_stream_t stream);
+
 /* ---- K1h: the same propagation step fed straight from the generator head's NHWC output ----------------------
  * Inside the models the two 1x1 heads of Generator.forward (models/components/spn.py:41-52,66-68; LRRU.py:238-247) run
  * as ONE 32-channel convolution; these entry points read its output where it lies and fold in what the reference does

@@ -30,6 +30,9 @@ SIGNATURES = {
     "jspsr_prop_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_prop_backward_f32": (c_i, [c_p] * 4 + [c_i] + [c_p] * 6 + [c_i, c_i, c_i, c_p]),
     "jspsr_prop_backward_fold_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "jspsr_prop_step_forward_f32": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_i, c_p, c_i, c_i, c_i, c_p]),
+    "jspsr_prop_step_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "jspsr_prop_step_backward_f32": (c_i, [c_p] * 4 + [c_i, c_p, c_f, c_i, c_i] + [c_p] * 6 + [c_i, c_i, c_i, c_p]),
     "jspsr_prop_head_forward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "jspsr_prop_head_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_prop_head_backward": (c_i, [c_i] + [c_p] * 8 + [c_i, c_i, c_i, c_p]),

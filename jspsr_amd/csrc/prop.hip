@@ -143,78 +143,6 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
   }
 }
 
-// Forward, prefetching form (one pixel per lane): the operand loads of ALL passes of the tile are issued before the DEM
-// tile is staged, so the staging round trip, the barrier and the operand round trips overlap instead of following one
-// another (3 dependent HBM round trips per workgroup -> 1), and every lane has NPASS x 26 loads in flight.
-template <int OC, int TH, int TW>
-__global__ __launch_bounds__(NT) void prop_fwd_pf_kernel(const float* __restrict__ dem,
-                                                        const float* __restrict__ weight,
-                                                        const float* __restrict__ offset,
-                                                        const float* __restrict__ wk,
-                                                        const float* __restrict__ b0, float scale,
-                                                        float* __restrict__ out, Geom g) {
-  constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
-  __shared__ __attribute__((aligned(16))) float lds[LH * LW];
-  constexpr int RPP = NT / TW;       // rows per pass
-  constexpr int NPASS = TH / RPP;
-  static_assert(TH % RPP == 0 && NPASS >= 1 && NPASS <= 4, "tile shape");
-  int b, ty0, tx0;
-  tile_coords(g, b, ty0, tx0);
-  const int H = g.H, W = g.W;
-  const size_t P = (size_t)H * W;
-  const float* img = dem + (size_t)b * P;
-  const int x = tx0 + (int)(threadIdx.x % TW);
-  const int yl = ty0 + (int)(threadIdx.x / TW);
-  float a[NPASS][9], oy[NPASS][9], ox[NPASS][9], dc[NPASS];
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int y = yl + p * RPP;
-    const bool ok = x < W && y < H;
-    const size_t pix = ok ? (size_t)y * W + x : 0;
-    const float* wp = weight + (size_t)b * 9 * P + pix;
-    const float* op = offset + (size_t)b * OC * P + pix;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      a[p][k] = ok ? wp[k * P] : 0.f;
-      if (OC == 18 || k != 4) {
-        oy[p][k] = ok ? op[(size_t)och<OC>(k, 0) * P] : 0.f;
-        ox[p][k] = ok ? op[(size_t)och<OC>(k, 1) * P] : 0.f;
-      } else {
-        oy[p][k] = ox[p][k] = 0.f;
-      }
-    }
-    dc[p] = ok ? img[pix] : 0.f;
-  }
-  stage_dem<LH, LW>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
-  float wreg[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
-  const float bias = b0[0];
-  __syncthreads();
-  const int ly0 = ty0 - HALO, lx0 = tx0 - HALO;
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int y = yl + p * RPP;
-    if (x < W && y < H) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s += a[p][k];
-      const float mean = s / 9.f;
-      float acc = bias;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float py = (float)(y - 1 + k / 3) + oy[p][k];
-        const float px = (float)(x - 1 + k % 3) + ox[p][k];
-        const Corners c = corners<LH, LW>(lds, img, H, W, ly0, lx0, py, px);
-        const float hy = 1.f - c.ly, hx = 1.f - c.lx;
-        const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
-        acc += wreg[k] * (a[p][k] - mean) * S;
-      }
-      out[(size_t)b * P + (size_t)y * W + x] = acc + scale * dc[p];
-    }
-  }
-}
-
 template <int OC, int PX, bool VEC, int TH, int TW>
 __global__ __launch_bounds__(NT) void prop_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ dem,
@@ -425,15 +353,6 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
   g.dem_vec4 = can_vec(W, 4, {dem});
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(g.nblk), block(NT);
-  static const int pf = env_int("JSPSR_PROP_PF", 0);
-  if (pf && px == 1 && g.tw * g.th <= 4 * NT) {
-    by_shape(offset_channels, 1, true, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
-      if constexpr (decltype(THc)::value * decltype(TWc)::value <= 4 * NT && decltype(PXc)::value == 1)
-        hipLaunchKernelGGL((prop_fwd_pf_kernel<decltype(OCc)::value, decltype(THc)::value, decltype(TWc)::value>),
-                           grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g);
-    });
-    return jspsr::check_launch("prop_forward");
-  }
   by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
     hipLaunchKernelGGL((prop_fwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
                                         decltype(THc)::value, decltype(TWc)::value>),

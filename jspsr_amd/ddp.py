@@ -169,3 +169,5 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src, group=group)
+    from . import ops
+    ops.invalidate_packed_weights()          # written through .data: torch's version counter did not move

@@ -110,6 +110,149 @@ def propagate(dem, weight, offset, w, b, scale: float = 1.0):
     return _Propagate.apply(dem, weight, offset, w, b, scale)
 
 
+# ---- K1s: chains of propagation steps (NLSPN-style: fixed affinities / offsets, N iterations) -----------------------
+def _step_forward(dem, weight, offset, w, b, scale, normalize, out):
+    B, _, H, W = dem.shape
+    lib = _lib.load()
+    _lib.check(lib.jspsr_prop_step_forward_f32(dem.data_ptr(), weight.data_ptr(), offset.data_ptr(), offset.shape[1],
+                                               w.data_ptr(), b.data_ptr(), float(scale), int(normalize), out.data_ptr(),
+                                               B, H, W, _stream()), "jspsr_prop_step_forward_f32")
+    return out
+
+
+def _step_backward(gout, dem, weight, offset, w, scale, normalize, accumulate, gweight, goffset, gdem, ws):
+    B, _, H, W = dem.shape
+    lib = _lib.load()
+    _lib.check(lib.jspsr_prop_step_backward_f32(gout.data_ptr(), dem.data_ptr(), weight.data_ptr(), offset.data_ptr(),
+                                                offset.shape[1], w.data_ptr(), float(scale), int(normalize), int(accumulate),
+                                                gweight.data_ptr(), goffset.data_ptr(),
+                                                gdem.data_ptr() if gdem is not None else None, None, None, ws.data_ptr(),
+                                                B, H, W, _stream()), "jspsr_prop_step_backward_f32")
+
+
+def _step_workspace(B, H, W, device):
+    n = _lib.load().jspsr_prop_step_backward_workspace_bytes(B, H, W)
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device)
+
+
+class _PropagateSteps(torch.autograd.Function):
+    """feat_{i+1} = sum_k aff_k bilinear(feat_i, p_k + offset_k), i = 0..n-1, with the SAME affinities and offsets in
+    every step (NLSPN.forward, models/components/nlspn.py:219-233; `_propagate_once` :177-187), optionally re-imposing
+    known pixels before every step (preserve_input, :221-224).  Returns every step's result (the reference's
+    `list_feat`).  Backward: the steps in reverse; each yields the gradient with respect to its input raster (bilinear
+    scatter, jspsr_prop_step_backward_f32) and ADDS its share to the gradients of the shared affinities / offsets."""
+
+    @staticmethod
+    def forward(ctx, feat, aff, offset, n_steps, mask_fix, feat_fix):
+        _need_gpu(feat, aff, offset)
+        B, one, H, W = feat.shape
+        oc = offset.shape[1]
+        if one != 1 or tuple(aff.shape) != (B, 9, H, W) or tuple(offset.shape) != (B, oc, H, W) or oc not in (16, 18):
+            raise ValueError(f"propagate_steps: bad shapes feat {tuple(feat.shape)} aff {tuple(aff.shape)} offset {tuple(offset.shape)}")
+        if n_steps < 1:
+            raise ValueError("propagate_steps: n_steps must be >= 1")
+        aff, offset = aff.contiguous(), offset.contiguous()
+        ones = torch.ones(9, device=feat.device)
+        zero = torch.zeros(1, device=feat.device)
+        cur, inputs, outs = feat.contiguous(), [], []
+        for _ in range(n_steps):
+            if mask_fix is not None:
+                cur = ((1.0 - mask_fix) * cur + mask_fix * feat_fix).contiguous()
+            inputs.append(cur)
+            cur = _step_forward(cur, aff, offset, ones, zero, 0.0, 0, torch.empty_like(cur))
+            outs.append(cur)
+        ctx.save_for_backward(aff, offset, ones, mask_fix, *inputs)
+        ctx.n = n_steps
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        aff, offset, ones, mask_fix = ctx.saved_tensors[:4]
+        inputs = ctx.saved_tensors[4:]
+        B, _, H, W = inputs[0].shape
+        gaff, goff = torch.empty_like(aff), torch.empty_like(offset)
+        ws = _step_workspace(B, H, W, aff.device)
+        g, gfix = None, None
+        first = _PropagateSteps._last(ctx, gouts)     # this step overwrites the shared gradient buffers, earlier ones add
+        if first < 0:
+            return None, None, None, None, None, None
+        for i in range(ctx.n - 1, -1, -1):
+            gi = gouts[i]
+            if gi is not None:
+                g = gi.contiguous() if g is None else g + gi
+            if g is None:
+                continue
+            gin = torch.zeros_like(inputs[i])
+            _step_backward(g.contiguous(), inputs[i], aff, offset, ones, 0.0, 0, i != first, gaff, goff, gin, ws)
+            if mask_fix is not None:
+                gfix = mask_fix * gin if gfix is None else gfix + mask_fix * gin
+                gin = (1.0 - mask_fix) * gin
+            g = gin
+        return g, gaff, goff, None, None, gfix
+
+    @staticmethod
+    def _last(ctx, gouts):
+        """Index of the first step processed in backward (the last one with an incoming gradient): it overwrites the
+        shared gradient buffers, the earlier steps accumulate."""
+        for i in range(ctx.n - 1, -1, -1):
+            if gouts[i] is not None:
+                return i
+        return -1
+
+
+def propagate_steps(feat, aff, offset, n_steps, mask_fix=None, feat_fix=None):
+    """-> list of the n_steps rasters.  feat (B,1,H,W) fp32 (differentiable), aff (B,9,H,W) normalised affinities incl.
+    the reference tap, offset (B,18,H,W) or (B,16,H,W)."""
+    if (mask_fix is None) != (feat_fix is None):
+        raise ValueError("propagate_steps: mask_fix and feat_fix go together")
+    return list(_PropagateSteps.apply(feat, aff, offset, int(n_steps), mask_fix, feat_fix))
+
+
+class _SampleTaps(torch.autograd.Function):
+    """conf_k = bilinear(conf, (y, x) + offset_k) for the 8 learned taps -- the 1x1 deform_conv2d calls that modulate
+    the affinities by the confidence (nlspn.py:104-154; `legacy`: the tap's window displacement is added, :118-125).
+    Eight launches of the step kernel with a one-hot tap weight; offsets are constants (the reference detaches them)."""
+
+    @staticmethod
+    def forward(ctx, conf, off16, legacy):
+        _need_gpu(conf, off16)
+        B, _, H, W = conf.shape
+        conf = conf.contiguous()
+        off = off16.detach().clone().contiguous()
+        if not legacy:      # the kernel adds the 3x3 window displacement itself: cancel it
+            for t in range(8):
+                k = t if t < 4 else t + 1
+                off[:, 2 * t] -= (k // 3 - 1)
+                off[:, 2 * t + 1] -= (k % 3 - 1)
+        ones9 = torch.ones(B, 9, H, W, device=conf.device)
+        zero = torch.zeros(1, device=conf.device)
+        out = torch.empty(8, B, 1, H, W, device=conf.device)     # one contiguous (B,1,H,W) raster per tap
+        hots = []
+        for t in range(8):
+            hot = torch.zeros(9, device=conf.device)
+            hot[t if t < 4 else t + 1] = 1.0
+            hots.append(hot)
+            _step_forward(conf, ones9, off, hot, zero, 0.0, 0, out[t])
+        ctx.save_for_backward(conf, off, ones9, *hots)
+        return out.permute(1, 0, 2, 3, 4).reshape(B, 8, H, W).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        conf, off, ones9 = ctx.saved_tensors[:3]
+        hots = ctx.saved_tensors[3:]
+        B, _, H, W = conf.shape
+        gconf = torch.zeros_like(conf)
+        scratch_w, scratch_o = torch.empty_like(ones9), torch.empty_like(off)
+        ws = _step_workspace(B, H, W, conf.device)
+        for t in range(8):
+            _step_backward(g[:, t:t + 1].contiguous(), conf, ones9, off, hots[t], 0.0, 0, 0, scratch_w, scratch_o, gconf, ws)
+        return gconf, None, None
+
+
+def sample_taps(conf, off16, legacy=False):
+    return _SampleTaps.apply(conf, off16, bool(legacy))
+
+
 # ---- K1h: propagation fed straight from the merged 1x1 head's NHWC output ---------------------------------------------
 HEAD_CHANNELS = 32
 
@@ -196,6 +339,37 @@ def propagate_head(dem, head, w, b, scale: float = 1.0):
 # NHWC layer operators: torch.autograd.Function shells around jspsr_amd.kernels (HIP).
 # Tensors are (B, H, W, C) contiguous, fp32 or bf16; parameters stay fp32 masters.
 # =============================================================================================
+
+
+# ---- packed weights: re-laid once per weight update, not once per use -------------------------------------------------
+# The kernels read weights k-contiguous per output channel in the compute dtype (jspsr_pack_weight).  Weights change
+# only in the optimizer step, so the packed copy of a Parameter is kept on the Parameter object and re-made when the
+# values may have changed: torch's in-place version counter (optimizers, load_state_dict, copy_) or this module's
+# `weights epoch`, which the writers that bypass the counter bump (FlatAdamW's HIP kernel, broadcast_module's writes
+# through .data).  Tensors that are not Parameters (merged heads, test operands) are packed on every use.
+_weights_epoch = 0
+
+
+def invalidate_packed_weights():
+    """Call after modifying parameters in a way torch's version counter does not see (raw-pointer kernels, `.data`)."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _packed(param, w, mode, c_pad, dtype):
+    if not isinstance(param, torch.nn.Parameter):
+        return K.pack_weight(w, mode, c_pad, dtype)
+    cache = param.__dict__.setdefault("_jspsr_packs", {})
+    key = (mode, c_pad, dtype, w.data_ptr())
+    hit = cache.get(key)
+    stamp = (param._version, _weights_epoch)
+    if hit is not None and hit[1] == stamp:
+        return hit[0]
+    if len(cache) > 8:
+        cache.clear()
+    packed = K.pack_weight(w, mode, c_pad, dtype)
+    cache[key] = (packed, stamp)
+    return packed
 
 
 def pad_channels(x: torch.Tensor, mult: int) -> torch.Tensor:
@@ -363,7 +537,7 @@ class _Conv(torch.autograd.Function):
             out = None
             if dest is not None:
                 out = dest[0].slice(dest[1], O, (B, (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1))
-            y = K.conv2d_forward(x, K.pack_weight(w, 0, Cp, cdt), bias_d, stride, pad, relu, stats=want_stats, out=out)
+            y = K.conv2d_forward(x, _packed(weight, w, 0, Cp, cdt), bias_d, stride, pad, relu, stats=want_stats, out=out)
             if want_stats:
                 y, st = y
                 ctx.cfg = (stride, pad, relu, transposed, bias is not None)
@@ -376,7 +550,7 @@ class _Conv(torch.autograd.Function):
                 raise ValueError("conv_transpose: only k3 s2 p1 op1 without channel padding is built")
             if dest is not None:
                 raise ValueError("conv_transpose: dest is not supported")
-            y = K.conv2d_dgrad(x, K.pack_weight(w, 1, Cp, cdt), (2 * H, 2 * W), 2, 1, bias=bias_d, relu=relu)
+            y = K.conv2d_dgrad(x, _packed(weight, w, 1, Cp, cdt), (2 * H, 2 * W), 2, 1, bias=bias_d, relu=relu)
         ctx.cfg = (stride, pad, relu, transposed, bias is not None)
         ctx.save_for_backward(x, w, y if relu else None)
         return y
@@ -406,14 +580,14 @@ class _Conv(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 if Cp != I:
                     raise RuntimeError("conv backward: gradient w.r.t. a channel-padded input is not supported")
-                dx = K.conv2d_dgrad(dz, K.pack_weight(w, 1, Cg, cdt), (H, W), stride, pad)
+                dx = K.conv2d_dgrad(dz, _packed(ctx.wparam, w, 1, Cg, cdt), (H, W), stride, pad)
             if ctx.needs_input_grad[1]:
                 dW = _wgrad_async(ctx.wparam, dz, x, O, I, KH, KW, stride, pad)
         else:
             I, O, KH, KW = w.shape
             if ctx.needs_input_grad[0]:
                 # d/dx of a transposed conv = ordinary stride-2 conv of the fine-grid gradient
-                dx = K.conv2d_forward(dz, K.pack_weight(w, 0, Cg, cdt), None, 2, 1, False)
+                dx = K.conv2d_forward(dz, _packed(ctx.wparam, w, 0, Cg, cdt), None, 2, 1, False)
             if ctx.needs_input_grad[1]:
                 dW = _wgrad_async(ctx.wparam, x, dz, I, O, KH, KW, 2, 1)
         return dx, dW, dbias, None, None, None, None, None, None
@@ -498,17 +672,17 @@ class _ResUnit(torch.autograd.Function):
         w1d, w2d = w1.detach().contiguous(), w2.detach().contiguous()
         g1d, b1d, g2d, b2d = g1.detach(), b1.detach(), g2.detach(), b2.detach()
 
-        def conv_bn(inp, wt, k, st, pad, gam, bet, rm, rv, mom, eps, tr, relu, res=None, rs=1.0, out=None):
-            z = K.conv2d_forward(inp, K.pack_weight(wt, 0, inp.shape[3], cdt), None, st, pad, False, stats=tr)
+        def conv_bn(inp, wt, k, st, pad, gam, bet, rm, rv, mom, eps, tr, relu, res=None, rs=1.0, out=None, par=None):
+            z = K.conv2d_forward(inp, _packed(par, wt, 0, inp.shape[3], cdt), None, st, pad, False, stats=tr)
             z, part = z if tr else (z, None)
             y, mean, invstd = K.bn_forward(z, gam, bet, rm, rv, mom, eps, tr, relu, res, rs, partial=part, out=out)
             return z, y, mean, invstd
 
-        z1, y1, m1, i1 = conv_bn(x, w1d, 3, stride, 1, g1d, b1d, rm1, rv1, mom1, eps1, tr1, True)
+        z1, y1, m1, i1 = conv_bn(x, w1d, 3, stride, 1, g1d, b1d, rm1, rv1, mom1, eps1, tr1, True, par=w1)
         if has_d:
             rmd, rvd, momd, epsd, trd = bns[2]
             wdd, gdd, bdd = wd.detach().contiguous(), gd.detach(), bd.detach()
-            zd, r, md, idd = conv_bn(x, wdd, 1, stride, 0, gdd, bdd, rmd, rvd, momd, epsd, trd, False)
+            zd, r, md, idd = conv_bn(x, wdd, 1, stride, 0, gdd, bdd, rmd, rvd, momd, epsd, trd, False, par=wd)
         else:
             if stride != 1 or O != I:
                 raise ValueError("res_unit: identity shortcut needs stride 1 and equal channel counts")
@@ -516,7 +690,7 @@ class _ResUnit(torch.autograd.Function):
             trd = False
             r = x
         out_v = dest[0].slice(dest[1], O, z1.shape[:3]) if dest is not None else None
-        z2, out, m2, i2 = conv_bn(y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale), out_v)
+        z2, out, m2, i2 = conv_bn(y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale), out_v, par=w2)
         ctx.cfg = (stride, float(scale), bool(act), has_d, tr1, tr2, trd)
         ctx.wparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (w1, w2, wd))
         ctx.bparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (g1, b1, g2, b2, gd, bd))
@@ -544,7 +718,7 @@ class _ResUnit(torch.autograd.Function):
             dres = dout
         p1, p2, pd = ctx.wparams
         dW2 = _wgrad_async(p2, dz2, y1, O, O, 3, 3, 1, 1)
-        dy1 = K.conv2d_dgrad(dz2, K.pack_weight(w2, 1, O, cdt), y1.shape[1:3], 1, 1)
+        dy1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), y1.shape[1:3], 1, 1)
         del dz2
         dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1, grads_into=sink1)
         if sink1 is not None:
@@ -567,10 +741,10 @@ class _ResUnit(torch.autograd.Function):
             if sinkd is not None:
                 _bn_ready(pgd, pbd)
             dWd = _wgrad_async(pd, dzd, x, O, Cin, 1, 1, stride, 0)
-            side = K.conv2d_dgrad(dzd, K.pack_weight(wd, 1, O, cdt), (H, W), stride, 0, addend=extra) if need_x else None
+            side = K.conv2d_dgrad(dzd, _packed(pd, wd, 1, O, cdt), (H, W), stride, 0, addend=extra) if need_x else None
         dx = None
         if need_x:
-            dx = K.conv2d_dgrad(dz1, K.pack_weight(w1, 1, O, cdt), (H, W), stride, 1, addend=K.nhwc(side))
+            dx = K.conv2d_dgrad(dz1, _packed(p1, w1, 1, O, cdt), (H, W), stride, 1, addend=K.nhwc(side))
         return (dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None, None, None, None, None)
 
 
@@ -588,7 +762,7 @@ def conv_bn_infer(x, weight, gamma, beta, bn, stride, pad, relu=False, res=None,
     out = None
     if dest is not None:
         out = dest[0].slice(dest[1], O, (B, (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1))
-    return K.conv2d_forward(x, K.pack_weight(weight.detach().contiguous(), 0, Cp, x.dtype), sh, stride, pad, relu, out=out,
+    return K.conv2d_forward(x, _packed(weight, weight.detach().contiguous(), 0, Cp, x.dtype), sh, stride, pad, relu, out=out,
                             scale=sc, addend=K.nhwc(res) if res is not None else None)
 
 
@@ -605,7 +779,7 @@ def conv_transpose_bn_infer(x, weight, gamma, beta, bn, relu=True, dest=None):
         raise ValueError("conv_transpose: only k3 s2 p1 op1 without channel padding is built")
     sc, sh = K.bn_fold(gamma.detach(), beta.detach(), rm, rv, eps, 1.0)
     out = dest[0].slice(dest[1], O, (B, 2 * H, 2 * W)) if dest is not None else None
-    return K.conv2d_dgrad(x, K.pack_weight(weight.detach().contiguous(), 1, Cp, x.dtype), (2 * H, 2 * W), 2, 1, bias=sh,
+    return K.conv2d_dgrad(x, _packed(weight, weight.detach().contiguous(), 1, Cp, x.dtype), (2 * H, 2 * W), 2, 1, bias=sh,
                           relu=relu, out=out, scale=sc)
 
 

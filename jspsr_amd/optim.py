@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from . import ops
 from .ddp import GradReducer
 
 
@@ -49,6 +50,7 @@ class FlatAdamW:
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.steps = 0
+        ops.invalidate_packed_weights()      # the parameters now live elsewhere
 
     @property
     def lr(self):
@@ -71,6 +73,7 @@ class FlatAdamW:
                                                 self.exp_avg.data_ptr() + lo * es, self.exp_avg_sq.data_ptr() + lo * es,
                                                 hi - lo, g["lr"], self.betas[0], self.betas[1], self.eps,
                                                 self.weight_decay, self.steps, stream), "jspsr_adamw_step")
+        ops.invalidate_packed_weights()      # the kernel wrote the parameters through raw pointers
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()

@@ -349,6 +349,44 @@ def gen_host_side(path):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_nlspn(path, conf_prop, preserve_input, affinity, prop_time=6, B=2, H=24, W=40, ch_g=8, seed=41, legacy=False):
+    """g8: the reference's own NLSPN class (models/components/nlspn.py), fp64, random guidance convolution (the
+    reference zero-initialises it, which would make every offset and affinity vanish), prop_time steps; stores all
+    inputs, every step's output and the gradients of mean(sum_i feat_i * probe_i) with respect to feat_init, the
+    guidance convolution and the confidence."""
+    import models.components.nlspn as ref_nlspn
+    args = types.SimpleNamespace(prop_time=prop_time, affinity=affinity, affinity_gamma=0.5, conf_prop=conf_prop,
+                                 preserve_input=preserve_input, legacy=legacy)
+    rs = np.random.RandomState(seed)
+    t = lambda *shape, s=1.0: torch.from_numpy(rs.standard_normal(shape) * s)
+    m = ref_nlspn.NLSPN(args, ch_g, 1, 3, 3).double()
+    with torch.no_grad():
+        m.conv_offset_aff.weight.copy_(t(24, ch_g, 3, 3, s=0.25))
+        m.conv_offset_aff.bias.copy_(t(24, s=0.5))
+        # the affinity rows: large enough that tanh(x / 100) spreads over (-1, 1) and the abs-sum clamp has both cases
+        m.conv_offset_aff.weight[16:] *= 60.0
+        m.conv_offset_aff.bias[16:] *= 60.0
+    feat = torch.from_numpy(rs.uniform(0.2, 1.0, (B, 1, H, W))).requires_grad_()
+    guid = t(B, ch_g, H, W)
+    conf = torch.from_numpy(rs.uniform(0.0, 1.0, (B, 1, H, W))).requires_grad_()
+    fix = torch.from_numpy(rs.uniform(0.2, 1.0, (B, 1, H, W)) * (rs.uniform(0, 1, (B, 1, H, W)) < 0.1))
+    res, lst, offset, aff, sc = m(feat, guid, conf if conf_prop else None, fix if preserve_input else None)
+    probes = [t(B, 1, H, W) for _ in lst]
+    sum((f * p).mean() for f, p in zip(lst, probes)).backward()
+    store = dict(feat=feat.detach().numpy(), guidance=guid.numpy(), confidence=conf.detach().numpy(), feat_fix=fix.numpy(),
+                 conv_w=m.conv_offset_aff.weight.detach().numpy(), conv_b=m.conv_offset_aff.bias.detach().numpy(),
+                 scale_const=sc.numpy(), offset=offset.detach().numpy(), aff=aff.detach().numpy(),
+                 steps=torch.cat(lst, 1).detach().numpy(), probes=torch.cat(probes, 1).numpy(),
+                 grad_feat=feat.grad.numpy(), grad_conv_w=m.conv_offset_aff.weight.grad.numpy(),
+                 grad_conv_b=m.conv_offset_aff.bias.grad.numpy(),
+                 grad_conf=(conf.grad if conf.grad is not None else torch.zeros_like(conf)).numpy(),
+                 grad_scale_const=(m.aff_scale_const.grad if m.aff_scale_const.grad is not None else torch.zeros(1)).numpy(),
+                 conf_prop=np.bool_(conf_prop), preserve_input=np.bool_(preserve_input), affinity=np.array(affinity),
+                 prop_time=np.int64(prop_time), legacy=np.bool_(legacy))
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref_jspsr, ref_spn = import_reference()
     out = os.path.join(REPO, "tests", "golden")
@@ -361,9 +399,12 @@ def main():
     if want("g0_init"):
         gen_init_stream(ref_jspsr, os.path.join(out, "g0_init_stream_msk_nf8.npz"), {"lr_dem": 1, "image": 3, "mask": 15}, 8, 7)
         gen_init_stream(ref_jspsr, os.path.join(out, "g0_init_stream_img_nf32.npz"), {"lr_dem": 1, "image": 3}, 32, 8)
+    if want("g8"):
+        gen_nlspn(os.path.join(out, "g8_nlspn_tgass_conf_fix.npz"), True, True, "TGASS")
+        gen_nlspn(os.path.join(out, "g8_nlspn_as_plain.npz"), False, False, "AS", prop_time=3, seed=42)
     if want("g7"):
         gen_host_side(os.path.join(out, "g7_host_side.npz"))
-    if not want("g1") and not want("g3") and not want("g4") and not want("g5") and not want("g6"):
+    if only and not any(want(g) for g in ("g1", "g3", "g4", "g5", "g6")):
         return
     gen_prop(ref_spn, os.path.join(out, "g1_postprocessor.npz"))
     img = {"lr_dem": 1, "image": 3}

@@ -129,6 +129,25 @@ def gradient_noise_floor(forward, sd, inputs, probe, g_ref, n_trials=2, n_roundi
     return {k: tuple(v) for k, v in floors.items()}
 
 
+SMOOTH = ("postprocessor.", "post_layer.", "Post_process.", ".conv_weight.")
+
+
+def gradient_tolerances(floor, factor=2.0):
+    """Per-parameter tolerance from the measured floors.  A ReLU-mask flip is a discrete event: a given draw either
+    hits one inside a sub-network or it does not, and the handful of oracle draws cannot visit every sub-network (seen
+    on the GPU: one flip in LRRU's last affinity encoder, whose own floor read 4e-6 because none of the draws flipped
+    there, while every other encoder's floor read 5e-3).  What the draws DO measure is what a flip costs in this
+    network: the median floor over all parameters.  Parameters behind at least one ReLU get
+    factor x max(own floor, that median); parameters whose gradient never crosses a ReLU or a sampler kink (tap
+    weights, affinity head: `SMOOTH`) keep factor x their own floor."""
+    med = float(np.median([v[1] for v in floor.values()]))
+    tol = {}
+    for k, v in floor.items():
+        smooth = any(s in k for s in SMOOTH)
+        tol[k] = factor * (v[1] if smooth else max(v[1], med)) + 1e-5
+    return tol
+
+
 # ---- bf16-storage emulation of the oracle: what ANY implementation that stores activations (and their gradients) in
 #      bf16 between layers does to the numbers -- the yardstick for the bf16 path's stated tolerances ----------------
 class _QuantBoth(torch.autograd.Function):

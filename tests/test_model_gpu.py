@@ -68,16 +68,18 @@ def test_model_matches_reference_fixture(golden_dir, name, ic):
     # moves under (a) an fp32 rounding of inputs and parameters, (b) evaluation in fp32 and (c) fp32-accumulation-sized
     # noise on every convolution output, scaled to the forward deviation this very run shows -- ReLU masks within
     # rounding of zero flip, and each flip changes gradient entries by O(1).  The HIP gradient must sit within
-    # 2x that floor (+1e-5 for parameters whose floor is ~0: tap weights, last-layer biases), parameter by parameter.
+    # 2x that floor, parameter by parameter (Fx.gradient_tolerances: a flip is a discrete event the few draws cannot
+    # place in every sub-network, so a parameter behind a ReLU is held to the larger of its own floor and the network's
+    # median floor; tap weights and the affinity head, which no ReLU separates from the output, to their own floor).
     dev = (pred.detach().cpu().double() - ref).abs().max().item()
     floor = Fx.gradient_noise_floor(fwd, sd64, in64, probe, g_ref, forward_dev=dev, pred_ref=ref)
+    tols = Fx.gradient_tolerances(floor)      # 2 x max(own floor, the network's median floor); smooth parameters: own floor
     worst = []
     for k, ref_g in g_ref.items():
         err = _rel(grads[k], ref_g)
-        tol = 2.0 * floor[k][1] + 1e-5
-        worst.append((err / tol, k, err, floor[k][1]))
+        worst.append((err / tols[k], k, err, tols[k]))
     worst.sort(reverse=True)
-    print(f"{name}: worst gradient error / derived tolerance: " + "; ".join(f"{k} {e:.2e}/{2 * f + 1e-5:.2e}" for _, k, e, f in worst[:4]))
+    print(f"{name}: worst gradient error / derived tolerance: " + "; ".join(f"{k} {e:.2e}/{t:.2e}" for _, k, e, t in worst[:4]))
     assert worst[0][0] < 1.0, worst[:5]
     for k in z.files:
         if k.startswith("buf:"):

@@ -39,7 +39,8 @@ def _check(z, model, pred, gt, forward=None, ref64=None):
             assert _rel(g_ref[k[5:]], z[k]) < 1e-7, k
     dev = (pred.detach().cpu().double() - ref).abs().max().item()
     floor = Fx.gradient_noise_floor(forward, sd64, in64, probe, g_ref, forward_dev=dev, pred_ref=ref)
-    worst = sorted(((_rel(grads[k], g) / (2.0 * floor[k][1] + 1e-5), k) for k, g in g_ref.items()), reverse=True)
+    tols = Fx.gradient_tolerances(floor)
+    worst = sorted(((_rel(grads[k], g) / tols[k], k) for k, g in g_ref.items()), reverse=True)
     assert worst[0][0] < 1.0, worst[:5]
 
 

@@ -84,22 +84,34 @@ def test_flat_adamw_second_lr_group_and_schedule():
 def test_flat_adamw_checkpoint_round_trip_is_bit_exact(tmp_path):
     """The reference saves optimizer.state_dict() with every improved model (main.py:246-252) and restores it on resume
     (utils/utils.py:394): save after 3 steps -> torch.save / torch.load -> fresh model + optimizer -> 3 more steps
-    must equal 6 uninterrupted steps bit for bit, with the parameter / gradient aliases into the flat buffers intact."""
+    must equal 6 uninterrupted steps bit for bit, with the parameter / gradient aliases into the flat buffers intact.
+    The toy model is element-wise on purpose: its gradients are bit-reproducible, so any difference is the optimizer's."""
     from jspsr_amd.ddp import GradReducer
     from jspsr_amd.optim import FlatAdamW, WarmupStepLR
     torch.manual_seed(2)
-    mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.ReLU(), torch.nn.Conv2d(8, 5, 1)).cuda()
-    x = torch.randn(4, 3, 9, 9, device="cuda")
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.randn(3, 1000))
+            self.b = torch.nn.Parameter(torch.randn(1000))
+            self.c = torch.nn.Parameter(torch.randn(7))
+
+        def forward(self, x):
+            return (torch.tanh(self.a * x) * self.b).sum(0) + self.c.repeat(143)[:1000]
+
+    x = torch.randn(3, 1000, device="cuda")
+    mk = lambda: Toy().cuda()
 
     def make(net):
         red = GradReducer(net.parameters())
-        opt = FlatAdamW(red, lr=1e-3, weight_decay=1e-6, lr_overrides={p: 3e-4 for p in net[2].parameters()})
+        opt = FlatAdamW(red, lr=1e-3, weight_decay=1e-6, lr_overrides={net.c: 3e-4})
         return red, opt, WarmupStepLR(opt, warmup_epoch=2, step_size=2, gamma=0.5)
 
     def steps(net, red, opt, sch, n):
         for _ in range(n):
             opt.zero_grad()
-            net(x).square().mean().backward()
+            (net(x) ** 2).mean().backward()
             red.finish()
             opt.step()
             sch.step()
