@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
         for (int k = 0; k < 9; ++k) {
           const float py = (float)(y - 1 + k / 3) + oy[k].v[j];
           const float px = (float)(x + j - 1 + k % 3) + ox[k].v[j];
-          const Corners c = corners<LH, LW>(lds, img, H, W, ly0, lx0, py, px);
+          const Corners c = corners_fast<LH, LW>(lds, img, H, W, ly0, lx0, py, px);
           const float hy = 1.f - c.ly, hx = 1.f - c.lx;
           const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
           const float dSdy = hx * (c.v10 - c.v00) + c.lx * (c.v11 - c.v01);
