@@ -102,7 +102,50 @@ def time_k1(model, inputs, iters=20):
         e1.record()
         e1.synchronize()
         res[name] = e0.elapsed_time(e1) / iters * 1e-3
+    # K1h: the entry the model itself uses (operands straight from the merged head's 32-channel NHWC output, in the
+    # model's storage dtype): same timing rules.  Two byte counts per launch: `moved` = what the layout makes the kernel
+    # touch (32 channels, 7 of them padding / the centre logit), `algorithmic` = the 25 operand elements + dem + out
+    # (+ their gradients) of SURVEY 8d in that dtype.
+    from jspsr_amd import _lib, kernels as K
+    lib = _lib.load()
+    hdt = model.compute_dtype
+    es = 2 if hdt == torch.bfloat16 else 4
+    nh = max(2, int(700e6 // (B * H * W * 32 * es)) + 1)
+    heads = [(1.5 * torch.randn(B, H, W, 32, device=dev, generator=g)).to(hdt) for _ in range(nh)]
+    gheads = [torch.empty_like(h) for h in heads]
+    hws = torch.empty(max(lib.jspsr_prop_head_backward_workspace_bytes(B, H, W), 16), dtype=torch.uint8, device=dev)
+    st = lambda: torch.cuda.current_stream().cuda_stream
+
+    def hfwd(i):
+        _lib.check(lib.jspsr_prop_head_forward(K._dt(heads[0]), dem.data_ptr(), heads[i % nh].data_ptr(), w.data_ptr(),
+                                               b.data_ptr(), 1.0, out.data_ptr(), B, H, W, st()), "jspsr_prop_head_forward")
+
+    def hbwd(i):
+        _lib.check(lib.jspsr_prop_head_backward(K._dt(heads[0]), gout.data_ptr(), dem.data_ptr(), heads[i % nh].data_ptr(),
+                                                w.data_ptr(), gheads[i % nh].data_ptr(), None, None, hws.data_ptr(),
+                                                B, H, W, st()), "jspsr_prop_head_backward")
+
+    for name, fn in (("hfwd", hfwd), ("hbwd", hbwd)):
+        for i in range(3):
+            fn(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        e1.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e-3
     px = B * H * W
+    head = {
+        "kernel": f"prop_head_kernel<{'bf16' if es == 2 else 'f32'}>", "dtype": "bf16" if es == 2 else "f32",
+        "fwd_us": round(res["hfwd"] * 1e6, 2), "bwd_us": round(res["hbwd"] * 1e6, 2),
+        "fwd_moved_GBs": round((32 * es + 8.0) * px / res["hfwd"] / 1e9, 1), "bwd_moved_GBs": round((64 * es + 8.0) * px / res["hbwd"] / 1e9, 1),
+        "fwd_algorithmic_GBs": round((25 * es + 8.0) * px / res["hfwd"] / 1e9, 1),
+        "bwd_algorithmic_GBs": round((50 * es + 8.0) * px / res["hbwd"] / 1e9, 1),
+        "note": "the in-model entry: replaces sigmoid + two NHWC->planar transposes + planar K1 (+ their backward passes) by one "
+                "launch each way; bytes per pixel moved: 32*es + 8 fwd, 64*es + 8 bwd",
+    }
     # 16-channel offset layout (the all-zero centre pair is not stored): 108 B/px fwd, 208 B/px bwd
     fb, bb = 108.0 * px, 208.0 * px
     bw_f, bw_b = fb / res["fwd"] / 1e9, bb / res["bwd"] / 1e9
@@ -119,6 +162,7 @@ def time_k1(model, inputs, iters=20):
         "forward": {"kernel": "prop_fwd_kernel<16>", "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get("fwd_bytes_per_launch") if traffic else None,
                     "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2)},
+        "head_entry": head,
         "note": "algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / "
                 "mean launch duration (events on the launch stream, back-to-back launches of that kernel alone; "
                 "us_per_call_with_fold adds the 10-workgroup fold launch of the backward C-ABI call); traffic = PMC "

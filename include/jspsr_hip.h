@@ -197,12 +197,17 @@ size_t jspsr_reduce_workspace_bytes(int dtype, int C, int nseg);
  * training != 0: batch statistics (biased var), running stats updated in place with `momentum`
  * (unbiased var), save_mean / save_invstd [C] written for the backward.  training == 0: running
  * stats are used (and copied to save_*).  ext_partial / ext_rows: statistics already accumulated by
- * jspsr_conv2d_forward (NULL / 0: this call makes its own pass over x). */
+ * jspsr_conv2d_forward (NULL / 0: this call makes its own pass over x).
+ * The shortcut of a projecting BasicBlock is itself conv1x1 -> BatchNorm (basics.py:118-119): instead of normalising
+ * it in a pass of its own, that BatchNorm is called with y == NULL and affine_out [2][C] (statistics, running stats
+ * and its per-channel scale | shift only), and the block's second BatchNorm takes the RAW conv1x1 output as `res`
+ * together with res_affine = that [2][C]:  y = [relu]( bn(x) * res_scale + (res * res_affine[0] + res_affine[1]) ). */
 int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, const void* res, int r_cs, int r_coff,
                      void* y, int y_cs, int y_coff, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, int training,
                      int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
-                     const float* ext_partial, int ext_rows, void* workspace, jspsr_stream_t stream);
+                     const float* ext_partial, int ext_rows, const float* res_affine, float* affine_out,
+                     void* workspace, jspsr_stream_t stream);
 
 /* BatchNorm in eval mode as a per-channel affine: scale = gamma / sqrt(var + eps) * res_scale,
  * shift = (beta - mean * gamma / sqrt(var + eps)) * res_scale. */

@@ -45,7 +45,7 @@ SIGNATURES = {
     "jspsr_conv2d_wgrad": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p, c_p]),
     "jspsr_reduce_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_bn_forward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
-                               c_i, c_f, c_p, c_p, c_ll, c_i, c_p, c_i, c_p, c_p]),
+                               c_i, c_f, c_p, c_p, c_ll, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
     "jspsr_bn_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_f,
                                 c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p]),
     "jspsr_act_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_ll, c_i, c_p, c_p]),

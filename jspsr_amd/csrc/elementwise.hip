@@ -265,11 +265,14 @@ __global__ __launch_bounds__(TX * TY) void bn_apply_kernel(const T* __restrict__
                                                           const T* __restrict__ res, int r_cs, int r_coff,
                                                           T* __restrict__ y, int y_cs, int y_coff,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float res_scale, int relu, RedGeom g) {
+                                                          const float* __restrict__ raff, float res_scale, int relu, RedGeom g) {
   constexpr int N = V<T>::N;
-  float sc[N], sh[N];
+  float sc[N], sh[N], rsc[N], rsh[N];
   const int c0 = lane_map<N>(g).c;
   if (c0 < g.C) { load_param<N>(scale + c0, sc); load_param<N>(shift + c0, sh); }
+  // raff: the residual operand is itself the pre-normalisation output of a BatchNorm (the 1x1 projection of a
+  // BasicBlock's shortcut): its per-channel (scale | shift) is applied here, in fp32, instead of in a pass of its own
+  if (raff && c0 < g.C) { load_param<N>(raff + c0, rsc); load_param<N>(raff + g.C + c0, rsh); }
   for_pixels<T>(g, [&](int, long long, long long pix, int c) {
     float f[N], r[N];
     load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, f);
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(TX * TY) void bn_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       float v = f[k] * sc[k] + sh[k];
-      if (res) v = v * res_scale + r[k];
+      if (res) v = v * res_scale + (raff ? r[k] * rsc[k] + rsh[k] : r[k]);
       if (relu) v = fmaxf(v, 0.f);
       f[k] = v;
     }
@@ -567,18 +570,20 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
                                 void* y, int y_cs, int y_coff, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, int training,
                                 int relu, float res_scale, float* save_mean, float* save_invstd, long long npix, int C,
-                                const float* ext_partial, int ext_rows, void* workspace, jspsr_stream_t stream) {
+                                const float* ext_partial, int ext_rows, const float* res_affine, float* affine_out,
+                                void* workspace, jspsr_stream_t stream) {
   if (int e = check_c(dtype, C, "bn_forward")) return e;
-  if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !workspace || npix <= 0)
+  if (!x || (!y && !affine_out) || !gamma || !beta || !save_mean || !save_invstd || !workspace || npix <= 0)
     return fail(JSPSR_EINVAL, "bn_forward: null pointer or empty tensor");
+  if (res_affine && !res) return fail(JSPSR_EINVAL, "bn_forward: res_affine without a residual operand");
   if (!training && (!running_mean || !running_var)) return fail(JSPSR_EINVAL, "bn_forward: eval mode needs running stats");
   const int vec = dtype == JSPSR_F32 ? 4 : 8;
   if (x_cs % vec || x_coff % vec || y_cs % vec || y_coff % vec || (res && (r_cs % vec || r_coff % vec)))
     return fail(JSPSR_EINVAL, "bn_forward: channel pitches/offsets must be multiples of %d", vec);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
-  float* scale = ws;
-  float* shift = ws + C;
+  float* scale = affine_out ? affine_out : ws;
+  float* shift = affine_out ? affine_out + C : ws + C;
   float* partial = ws + 2 * C;
   int rows = 0;
   if (training && ext_partial) {
@@ -602,10 +607,11 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, rows, C, npix, gamma, beta,
                      running_mean, running_var, momentum, eps, training, save_mean, save_invstd, scale, shift);
   if (int e = check_launch("bn_finalize")) return e;
+  if (!y) return JSPSR_OK;      // statistics + (scale | shift) only: the consumer applies them (res_affine)
   const RedGeom ga = make_red(npix, 1, C, vec);
   DISPATCH(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, red_grid(ga, vec), dim3(TX, TY), 0, s,
                                      static_cast<const T*>(x), x_cs, x_coff, static_cast<const T*>(res), r_cs, r_coff,
-                                     static_cast<T*>(y), y_cs, y_coff, scale, shift, res_scale, relu, ga));
+                                     static_cast<T*>(y), y_cs, y_coff, scale, shift, res_affine, res_scale, relu, ga));
   return check_launch("bn_apply");
 }
 

@@ -180,12 +180,15 @@ def _workspace(dtype_code: int, C: int, nseg: int, device) -> torch.Tensor:
 
 
 def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, training, relu=False, res=None,
-               res_scale=1.0, out=None, out_coff=0, partial=None):
+               res_scale=1.0, out=None, out_coff=0, partial=None, res_affine=None, stats_only=False):
     """x (B,H,W,C) -> y = [relu](bn(x)*res_scale + res); returns (y, save_mean, save_invstd).
-    partial: (rows, 2, C) statistics from conv2d_forward(stats=True) -- skips the statistics pass."""
+    partial: (rows, 2, C) statistics from conv2d_forward(stats=True) -- skips the statistics pass.
+    stats_only: no output tensor; returns (affine, save_mean, save_invstd) with affine (2, C) fp32 = this BatchNorm's
+    per-channel (scale | shift) for a consumer to apply.  res_affine: such an affine for the residual operand."""
     _chk_s(x, "bn_forward")
     B, H, W, C = x.shape
-    if out is None:
+    affine = torch.empty((2, C), dtype=torch.float32, device=x.device) if stats_only else None
+    if out is None and not stats_only:
         out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -193,16 +196,19 @@ def bn_forward(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
     ws = _workspace(dt, C, 1, x.device)
     lib = _lib.load()
     _lib.check(lib.jspsr_bn_forward(dt, x.data_ptr(), pitch(x), 0, res.data_ptr() if res is not None else None,
-                                    pitch(res) if res is not None else 0, 0, out.data_ptr(), pitch(out), out_coff,
+                                    pitch(res) if res is not None else 0, 0, out.data_ptr() if out is not None else None,
+                                    pitch(out) if out is not None else 0, out_coff,
                                     gamma.data_ptr(), beta.data_ptr(),
                                     running_mean.data_ptr() if running_mean is not None else None,
                                     running_var.data_ptr() if running_var is not None else None,
                                     float(momentum), float(eps), int(training), int(relu), float(res_scale),
                                     mean.data_ptr(), invstd.data_ptr(), B * H * W, C,
                                     partial.data_ptr() if partial is not None else None,
-                                    partial.shape[0] if partial is not None else 0, ws.data_ptr(), _stream()),
+                                    partial.shape[0] if partial is not None else 0,
+                                    res_affine.data_ptr() if res_affine is not None else None,
+                                    affine.data_ptr() if affine is not None else None, ws.data_ptr(), _stream()),
                "jspsr_bn_forward")
-    return out, mean, invstd
+    return (affine if stats_only else out), mean, invstd
 
 
 def bn_fold(gamma, beta, running_mean, running_var, eps, res_scale=1.0):

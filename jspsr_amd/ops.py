@@ -647,6 +647,9 @@ def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
                             partial, dest)
 
 
+fold_shortcut_bn = os.environ.get("JSPSR_BN_FOLD_SHORTCUT", "1") != "0"   # A/B switch (Switches)
+
+
 class _ResUnit(torch.autograd.Function):
     """One BasicBlock (basics.py:88-123) as a single autograd node:
 
@@ -672,25 +675,36 @@ class _ResUnit(torch.autograd.Function):
         w1d, w2d = w1.detach().contiguous(), w2.detach().contiguous()
         g1d, b1d, g2d, b2d = g1.detach(), b1.detach(), g2.detach(), b2.detach()
 
-        def conv_bn(inp, wt, k, st, pad, gam, bet, rm, rv, mom, eps, tr, relu, res=None, rs=1.0, out=None, par=None):
+        def conv_bn(inp, wt, k, st, pad, gam, bet, rm, rv, mom, eps, tr, relu, res=None, rs=1.0, out=None, par=None,
+                    res_affine=None, stats_only=False):
             z = K.conv2d_forward(inp, _packed(par, wt, 0, inp.shape[3], cdt), None, st, pad, False, stats=tr)
             z, part = z if tr else (z, None)
-            y, mean, invstd = K.bn_forward(z, gam, bet, rm, rv, mom, eps, tr, relu, res, rs, partial=part, out=out)
+            y, mean, invstd = K.bn_forward(z, gam, bet, rm, rv, mom, eps, tr, relu, res, rs, partial=part, out=out,
+                                           res_affine=res_affine, stats_only=stats_only)
             return z, y, mean, invstd
 
         z1, y1, m1, i1 = conv_bn(x, w1d, 3, stride, 1, g1d, b1d, rm1, rv1, mom1, eps1, tr1, True, par=w1)
         if has_d:
             rmd, rvd, momd, epsd, trd = bns[2]
             wdd, gdd, bdd = wd.detach().contiguous(), gd.detach(), bd.detach()
-            zd, r, md, idd = conv_bn(x, wdd, 1, stride, 0, gdd, bdd, rmd, rvd, momd, epsd, trd, False, par=wd)
+            # the projection's BatchNorm is not applied in a pass of its own: its (scale | shift) rides into bn2's apply,
+            # which reads the raw 1x1 output as the residual operand (jspsr_bn_forward: res_affine / affine_out)
+            if fold_shortcut_bn:
+                zd, r_aff, md, idd = conv_bn(x, wdd, 1, stride, 0, gdd, bdd, rmd, rvd, momd, epsd, trd, False, par=wd, stats_only=True)
+                r = zd
+            else:
+                zd, r, md, idd = conv_bn(x, wdd, 1, stride, 0, gdd, bdd, rmd, rvd, momd, epsd, trd, False, par=wd)
+                r_aff = None
         else:
+            r_aff = None
             if stride != 1 or O != I:
                 raise ValueError("res_unit: identity shortcut needs stride 1 and equal channel counts")
             wdd = gdd = bdd = zd = md = idd = None
             trd = False
             r = x
         out_v = dest[0].slice(dest[1], O, z1.shape[:3]) if dest is not None else None
-        z2, out, m2, i2 = conv_bn(y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale), out_v, par=w2)
+        z2, out, m2, i2 = conv_bn(y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale), out_v, par=w2,
+                                  res_affine=r_aff)
         ctx.cfg = (stride, float(scale), bool(act), has_d, tr1, tr2, trd)
         ctx.wparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (w1, w2, wd))
         ctx.bparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (g1, b1, g2, b2, gd, bd))
