@@ -138,6 +138,24 @@ int jspsr_prop_head_backward(int dtype, const float* grad_out, const float* dem,
 int jspsr_pack_weight(int dtype, const float* w, void* packed, int O, int I, int KH, int KW,
                       int mode, int c_pad, jspsr_stream_t stream);
 
+/* The same re-lay for MANY weights in one launch (after an optimizer step: 76 conv weights x 2 layouts for the
+ * image+mask JSPSR instead of 152 launches).  `descs` is DEVICE memory, n descriptors sorted by `start`; descriptor i
+ * is served by workgroups [start, start + ceil(total / jspsr_pack_chunk())) of the launch, total = rows * KH * KW *
+ * c_pad elements; total_blocks = the sum of those block counts.  Each descriptor names its own output dtype. */
+typedef struct jspsr_pack_desc {
+  const float* w;     /* (O, I, KH, KW) fp32 master */
+  void* out;          /* packed output */
+  long long start;    /* first workgroup of this descriptor = sum of ceil(total / jspsr_pack_chunk()) over the preceding ones */
+  long long total;    /* elements of this packed output */
+  int O, I, KH, KW;
+  int mode;           /* 0 / 1 as for jspsr_pack_weight */
+  int c_pad;
+  int dtype;          /* JSPSR_F32 / JSPSR_BF16 */
+  int reserved;
+} jspsr_pack_desc;
+int jspsr_pack_chunk(void);
+int jspsr_pack_weights_multi(const jspsr_pack_desc* descs, int n, long long total_blocks, jspsr_stream_t stream);
+
 /* out[b,oy,ox,n] = bias[n] + sum_{ky,kx,c} in[b, oy*stride-pad+ky, ox*stride-pad+kx, c] * W[n,ky,kx,c]
  * (+ ReLU if relu != 0).  wpack: mode-0 packing with c_pad = Cin.  bias may be NULL.
  * stats (may be NULL; requires bias == NULL and relu == 0): the epilogue also writes the BatchNorm batch

@@ -37,6 +37,8 @@ SIGNATURES = {
     "jspsr_prop_head_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_prop_head_backward": (c_i, [c_i] + [c_p] * 8 + [c_i, c_i, c_i, c_p]),
     "jspsr_pack_weight": (c_i, [c_i, c_p, c_p] + [c_i] * 6 + [c_p]),
+    "jspsr_pack_chunk": (c_i, []),
+    "jspsr_pack_weights_multi": (c_i, [c_p, c_i, c_ll, c_p]),
     "jspsr_conv2d_stats_rows": (c_i, [c_i, c_i, c_i]),
     "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p, c_p, c_p, c_i, c_p]),
     "jspsr_bn_fold": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p]),

@@ -866,7 +866,46 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// All conv weights of a model in ONE launch (after the optimizer step).  Descriptor i owns blocks
+// [blk0_i, blk0_{i+1}) of PACK_CHUNK elements each (`start` holds blk0, in blocks); a block finds its descriptor once
+// (binary search over <= a few hundred entries, wave-uniform), then walks its chunk like pack_weight_kernel.
+constexpr int PACK_CHUNK = 2048;
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const jspsr_pack_desc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;
+  const long long b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].start <= b) lo = mid; else hi = mid - 1;
+  }
+  const jspsr_pack_desc d = descs[lo];
+  const long long l0 = (b - d.start) * PACK_CHUNK;
+  const float* __restrict__ w = d.w;
+#pragma unroll
+  for (int k = 0; k < PACK_CHUNK / 256; ++k) {
+    const long long l = l0 + k * 256 + threadIdx.x;
+    if (l >= d.total) break;
+    const int c = (int)(l % d.c_pad);
+    long long r = l / d.c_pad;
+    const int kx = (int)(r % d.KW); r /= d.KW;
+    const int ky = (int)(r % d.KH); r /= d.KH;
+    const int nn = (int)r;
+    float v = 0.f;
+    if (d.mode == 0) { if (c < d.I) v = w[(((size_t)nn * d.I + c) * d.KH + ky) * d.KW + kx]; }
+    else             { if (c < d.O) v = w[(((size_t)c * d.I + nn) * d.KH + ky) * d.KW + kx]; }
+    if (d.dtype == JSPSR_F32) static_cast<float*>(d.out)[l] = v;
+    else static_cast<__bf16*>(d.out)[l] = (__bf16)v;
+  }
+}
+
 }  // namespace
+
+extern "C" int jspsr_pack_weights_multi(const jspsr_pack_desc* descs, int n, long long total_blocks, jspsr_stream_t stream) {
+  if (!descs || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return fail(JSPSR_EINVAL, "pack_weights_multi: bad arguments");
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), descs, n);
+  return check_launch("pack_weights_multi");
+}
+
+extern "C" int jspsr_pack_chunk(void) { return PACK_CHUNK; }
 
 extern "C" int jspsr_pack_weight(int dtype, const float* w, void* packed, int O, int I, int KH, int KW,
                                  int mode, int c_pad, jspsr_stream_t stream) {

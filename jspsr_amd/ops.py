@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import collections
 import os
+import weakref
 
 import torch
 
@@ -356,6 +357,14 @@ def invalidate_packed_weights():
     _weights_epoch += 1
 
 
+# Re-making all packed copies in ONE launch right after the optimizer step removes 152 small launches per step, but
+# measured no faster (65.4 vs 65.2 ms at 8 tiles, 21.1 vs 21.0 ms at 2): the per-use pack kernels run on the branch /
+# weight-gradient streams beside real work, the single launch sits on the main stream's critical path.  Off by default.
+repack_after_step = os.environ.get("JSPSR_REPACK_ALL", "0") != "0"
+_pack_registry = {}      # id(param) -> weakref(param): every Parameter that holds cached packs
+_pack_table = None       # (signature, device descriptor tensor, grand_total) of the last repack_all()
+
+
 def _packed(param, w, mode, c_pad, dtype):
     if not isinstance(param, torch.nn.Parameter):
         return K.pack_weight(w, mode, c_pad, dtype)
@@ -369,7 +378,46 @@ def _packed(param, w, mode, c_pad, dtype):
         cache.clear()
     packed = K.pack_weight(w, mode, c_pad, dtype)
     cache[key] = (packed, stamp)
+    if id(param) not in _pack_registry:
+        _pack_registry[id(param)] = weakref.ref(param, lambda _, k=id(param): _pack_registry.pop(k, None))
     return packed
+
+
+def repack_all():
+    """Re-lay EVERY cached packed weight from its (just updated) master in one launch and mark the copies current.
+    FlatAdamW.step() calls this right after its kernel: the 2 x 76 per-use pack launches of the next step disappear
+    (jspsr_pack_weights_multi).  Runs on the current stream, which by then is ordered after every stream that read the
+    old copies (GradReducer.finish() joins them before the optimizer)."""
+    global _pack_table
+    import numpy as np
+    entries = []
+    for ref in list(_pack_registry.values()):
+        p = ref()
+        if p is None or not p.is_cuda:
+            continue
+        for (mode, c_pad, dtype, ptr), (packed, _) in p.__dict__.get("_jspsr_packs", {}).items():
+            if ptr == p.data_ptr() and p.dim() == 4 and p.is_contiguous():
+                entries.append((p, mode, c_pad, dtype, packed))
+    if not entries:
+        return 0
+    sig = tuple((p.data_ptr(), packed.data_ptr(), mode, c_pad) for p, mode, c_pad, _, packed in entries)
+    if _pack_table is None or _pack_table[0] != sig:
+        desc = np.zeros(len(entries), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("start", "<i8"), ("total", "<i8"),
+                                                      ("O", "<i4"), ("I", "<i4"), ("KH", "<i4"), ("KW", "<i4"), ("mode", "<i4"),
+                                                      ("c_pad", "<i4"), ("dtype", "<i4"), ("reserved", "<i4")]))
+        start, chunk = 0, _lib.load().jspsr_pack_chunk()
+        for i, (p, mode, c_pad, dtype, packed) in enumerate(entries):
+            O, I, KH, KW = p.shape
+            total = packed.numel()
+            desc[i] = (p.data_ptr(), packed.data_ptr(), start, total, O, I, KH, KW, mode, c_pad, K._dt(packed), 0)
+            start += (total + chunk - 1) // chunk            # workgroups serving this descriptor
+        table = torch.from_numpy(desc.view(np.uint8).copy()).to(entries[0][0].device)
+        _pack_table = (sig, table, start)
+    _, table, grand = _pack_table
+    _lib.check(_lib.load().jspsr_pack_weights_multi(table.data_ptr(), len(entries), grand, _stream()), "jspsr_pack_weights_multi")
+    for p, mode, c_pad, dtype, packed in entries:
+        p.__dict__["_jspsr_packs"][(mode, c_pad, dtype, p.data_ptr())] = (packed, (p._version, _weights_epoch))
+    return len(entries)
 
 
 def pad_channels(x: torch.Tensor, mult: int) -> torch.Tensor:

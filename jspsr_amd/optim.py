@@ -73,7 +73,9 @@ class FlatAdamW:
                                                 self.exp_avg.data_ptr() + lo * es, self.exp_avg_sq.data_ptr() + lo * es,
                                                 hi - lo, g["lr"], self.betas[0], self.betas[1], self.eps,
                                                 self.weight_decay, self.steps, stream), "jspsr_adamw_step")
-        ops.invalidate_packed_weights()      # the kernel wrote the parameters through raw pointers
+        ops.invalidate_packed_weights()      # the kernel wrote the parameters through raw pointers ...
+        if ops.repack_after_step:
+            ops.repack_all()                 # ... and every cached packed copy is re-made here, in one launch
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()

@@ -362,3 +362,36 @@ print("variants ok")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
                        timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "variants ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_packed_weight_cache_and_single_launch_repack():
+    """ops._packed keeps the re-laid copy of a Parameter until its values can have changed (torch's version counter, or
+    the module's weights epoch for writers that bypass it); ops.repack_all() re-makes every cached copy in ONE launch
+    (jspsr_pack_weights_multi) -- bit-identical to per-tensor jspsr_pack_weight, both layouts, both dtypes."""
+    from jspsr_amd import ops
+    K = _k()
+    g_ = torch.Generator().manual_seed(21)
+    params = [torch.nn.Parameter(torch.randn(s, generator=g_).cuda()) for s in ((24, 16, 3, 3), (8, 40, 1, 1), (32, 8, 5, 5))]
+    cases = []
+    for p in params:
+        for mode, dt in ((0, torch.bfloat16), (1, torch.bfloat16), (0, torch.float32), (1, torch.float32)):
+            cpad = (p.shape[1] if mode == 0 else p.shape[0])
+            cpad = (cpad + 7) // 8 * 8
+            a = ops._packed(p, p.detach(), mode, cpad, dt)
+            assert ops._packed(p, p.detach(), mode, cpad, dt) is a           # cached
+            assert torch.equal(a, K.pack_weight(p.detach(), mode, cpad, dt))
+            cases.append((p, mode, cpad, dt, a))
+    with torch.no_grad():
+        for p in params:
+            p.data.mul_(1.5)                       # through .data: the version counter does not move
+    ops.invalidate_packed_weights()
+    n = ops.repack_all()                       # what FlatAdamW.step() does when JSPSR_REPACK_ALL=1
+    assert n >= len(cases)
+    for p, mode, cpad, dt, a in cases:
+        b = ops._packed(p, p.detach(), mode, cpad, dt)
+        assert b is a, "repack_all refreshes the cached tensors in place"
+        assert torch.equal(b, K.pack_weight(p.detach(), mode, cpad, dt))
+    with torch.no_grad():
+        params[0].add_(1.0)                        # an ordinary in-place update: seen through the version counter
+    c = ops._packed(params[0], params[0].detach(), 0, 16, torch.bfloat16)
+    assert torch.equal(c, K.pack_weight(params[0].detach(), 0, 16, torch.bfloat16))
