@@ -119,7 +119,6 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
         for (int j = 0; j < PX; ++j) oy[k].v[j] = ox[k].v[j] = 0.f;
       }
     }
-    const Vec<PX> dc = ldv<PX, VEC>(img + pix, x, W);
     Vec<PX> o;
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
         const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
         acc += wreg[k] * (a[k].v[j] - mean) * S;
       }
-      o.v[j] = acc + scale * dc.v[j];
+      o.v[j] = acc + scale * lds[(y - ly0) * LW + (x + j - lx0)];   // the residual term reads dem[y][x] from the staged tile
     }
     stv<PX, VEC>(out + (size_t)b * P + pix, o, x, W);
   }
