@@ -382,6 +382,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
+    # host side of one step: C-ABI calls issued and the time the host needs to enqueue them (no synchronisation inside)
+    torch.cuda.synchronize()
+    c0, h0 = _lib.calls, time.perf_counter()
+    step()
+    host_ms, abi_calls = (time.perf_counter() - h0) * 1e3, _lib.calls - c0
+    torch.cuda.synchronize()
 
     fp32 = None
     if world == 1 and args.dtype == "bf16" and not args.no_fp32:
@@ -417,6 +423,9 @@ def main():
                 "tiles_per_gpu": args.batch, "tile": TILE, "global_tiles": args.batch * world,
                 "parallelism": f"dp{world}", "final_loss": round(final_loss, 6),
             },
+            "host": {"abi_calls_per_step": abi_calls, "enqueue_ms_per_step": round(host_ms, 2),
+                     "note": "C-ABI entry points called per step (each launches 1-3 kernels) and the host time to enqueue "
+                             "them; enqueue_ms well under ms_per_step = the step is GPU-bound (no graph capture needed)"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "fp32": fp32,

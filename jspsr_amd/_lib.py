@@ -97,7 +97,12 @@ def load():
     return _lib
 
 
+calls = 0   # C-ABI calls checked so far (bench.py reports calls per step; an entry point launches 1-3 kernels)
+
+
 def check(code: int, what: str):
+    global calls
+    calls += 1
     if code != 0:
         msg = load().jspsr_last_error().decode(errors="replace")
         raise JspsrHipError(f"{what} failed (code {code}): {msg}")
