@@ -277,6 +277,18 @@ int jspsr_loss_backward(const float* pred, const float* gt, const float* grad_to
                         float wg, float* grad_pred, const void* workspace, int B, int H, int W,
                         jspsr_stream_t stream);
 
+/* Evaluation scores of one tile on the device (evaluation/metrics.py: MeterBase._prepare :147-199, MeterPSNR :229-235,
+ * MeterRMSE :372-384, MeterMedian :453, MeterNMAD :508-510, MeterLE95 :565-568; ToDEM.descale_data,
+ * data/data_utils.py:441-457).  pred, gt: fp32 [H][W] in the network's [0,1] range (the reference evaluates one tile
+ * at a time).  border: fraction cropped on every side (int(H * border) rows, int(W * border) columns); the prediction is
+ * clamped to [0,1]; both are de-scaled to metres with (value_min, value_max, elev_log).
+ * scores[5] (device) = {PSNR on the [0,1] tensors, RMSE, median, NMAD, LE95 of the elevation differences}.  The order
+ * statistics are exact (radix select; torch.median's lower-middle convention, kthvalue with k = 1 + round(0.95 (n-1))).
+ * No host synchronisation.  workspace: jspsr_metrics_workspace_bytes(H, W) bytes, 16-byte aligned. */
+size_t jspsr_metrics_workspace_bytes(int H, int W);
+int jspsr_metrics_forward(const float* pred, const float* gt, int H, int W, float border, float value_min,
+                          float value_max, int elev_log, float* scores, void* workspace, jspsr_stream_t stream);
+
 /* One AdamW step (torch.optim.AdamW semantics: decoupled weight decay, bias correction) over a flat
  * fp32 parameter / gradient / moment buffer of n elements (utils/common_config.py:241-291).  The four pointers are
  * 4-byte aligned and share one offset from a 16-byte boundary (sub-ranges of four identically laid out buffers). */

@@ -58,6 +58,8 @@ SIGNATURES = {
     "jspsr_loss_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_loss_forward": (c_i, [c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_p]),
     "jspsr_loss_backward": (c_i, [c_p, c_p, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "jspsr_metrics_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
+    "jspsr_metrics_forward": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),
     "jspsr_adamw_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, c_p]),
 }
 

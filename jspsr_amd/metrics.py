@@ -14,6 +14,8 @@ from math import log
 
 import torch
 
+from . import _lib
+
 
 def scale_data(z, elev_min, elev_max, elev_log=False, base_elev=0.0):
     """metres -> network range (data_utils.py:289-312)."""
@@ -63,9 +65,28 @@ def le95(dh):
     return torch.kthvalue(dh.abs().flatten(), k).values
 
 
+def tile_scores(pred, gt, value_min, value_max, border=0.05, elev_log=True):
+    """All five scores of ONE tile (1,1,H,W) on the GPU in one C-ABI call (jspsr_metrics_forward: fused crop / clamp /
+    de-scale / reductions + an exact radix select for the three order statistics) -> device tensor
+    (PSNR, RMSE, median, NMAD, LE95).  No host synchronisation."""
+    if not pred.is_cuda or pred.shape != gt.shape or pred.numel() != pred.shape[-1] * pred.shape[-2]:
+        raise ValueError("tile_scores: one (1,1,H,W) GPU tile per call")
+    H, W = pred.shape[-2:]
+    p, g = pred.float().contiguous(), gt.float().contiguous()
+    lib = _lib.load()
+    ws = torch.empty(lib.jspsr_metrics_workspace_bytes(H, W), dtype=torch.uint8, device=pred.device)
+    out = torch.empty(5, dtype=torch.float32, device=pred.device)
+    _lib.check(lib.jspsr_metrics_forward(p.data_ptr(), g.data_ptr(), H, W, float(border), float(value_min), float(value_max),
+                                         int(bool(elev_log)), out.data_ptr(), ws.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "jspsr_metrics_forward")
+    return out
+
+
 class Meter:
     """Running per-sample averages of all five scores (what PerformanceMeter.get_score reports,
-    evaluation/evaluate_utils.py:26-47).  Accumulates on the device; one host sync in ``scores()``."""
+    evaluation/evaluate_utils.py:26-47).  Accumulates on the device; one host sync in ``scores()``.
+    GPU tiles of batch size 1 (how the reference evaluates) go through the fused HIP path (`tile_scores`); CPU tensors
+    and larger batches through the same formulas as torch operators."""
 
     NAMES = ("PSNR", "RMSE", "Median", "NMAD", "LE95")
 
@@ -75,6 +96,11 @@ class Meter:
 
     @torch.no_grad()
     def update(self, pred, gt):
+        if pred.is_cuda and pred.dim() == 4 and pred.shape[0] == 1 and pred.shape[1] == 1:
+            vals = tile_scores(pred, gt, self.vmin, self.vmax, self.border, self.elev_log)
+            self.sums = vals if self.sums is None else self.sums + vals
+            self.n += 1
+            return
         p, g = prepare(pred.float(), gt.float(), self.border)
         dh = descale_data(p, self.vmin, self.vmax, self.elev_log) - descale_data(g, self.vmin, self.vmax, self.elev_log)
         vals = torch.stack((psnr(p, g), rmse(dh), median(dh), nmad(dh), le95(dh)))

@@ -162,3 +162,52 @@ def test_init_stream_equals_reference(golden_dir, name):
         t = sd[k].double().reshape(-1)
         got = np.array([t.sum().item(), t.abs().sum().item(), t[0].item(), t[-1].item()])
         assert np.array_equal(got, z["summary"][i]), k
+
+
+@pytest.mark.gpu
+def test_fused_tile_scores_match_the_torch_composition_and_the_reference(g7):
+    """jspsr_metrics_forward (one C-ABI call per tile: crop / clamp / de-scale / reductions + radix select) against
+    (a) the reference-made meter numbers (through Meter, above), (b) the same formulas as torch operators on the same
+    device tensors: the three order statistics must be BIT-identical (an exact select returns an element of the
+    array), PSNR / RMSE within fp32 summation error; sizes incl. odd ones and a 1024 x 768 tile."""
+    vmin, vmax = float(g7["vmin"]), float(g7["vmax"])
+    g_ = torch.Generator().manual_seed(9)
+    cases = [(torch.from_numpy(g7["meter_pred"][i:i + 1]), torch.from_numpy(g7["meter_gt"][i:i + 1])) for i in range(3)]
+    for H, W in ((37, 53), (128, 128), (1024, 768)):
+        z = 300 * torch.rand(1, 1, H, W, generator=g_)
+        gt = M.scale_data(z, vmin, vmax, True)
+        pred = M.scale_data((z + 2 * torch.randn(z.shape, generator=g_)).clamp_min(-70), vmin, vmax, True)
+        pred[0, 0, H // 2, W // 2] = 1.3
+        cases.append((pred, gt))
+    for pred, gt in cases:
+        for border in (0.05, 0.0):
+            for lg in (True, False):
+                p, g = pred.cuda(), gt.cuda()
+                got = M.tile_scores(p, g, vmin, vmax, border, lg).cpu()
+                pp, gg = M.prepare(p.float(), g.float(), border)
+                dh = M.descale_data(pp, vmin, vmax, lg) - M.descale_data(gg, vmin, vmax, lg)
+                want = torch.stack((M.psnr(pp, gg), M.rmse(dh), M.median(dh), M.nmad(dh), M.le95(dh))).cpu()
+                assert abs(got[0] - want[0]) < 1e-3 and abs(got[1] - want[1]) < 1e-4 * abs(want[1]) + 1e-6
+                # the device exp/log of the fused kernel and torch's agree to 1 ulp of a ~900 m elevation (6e-5 m); the
+                # select itself is exact: compare through a tolerance of 2 ulp of the de-scaled magnitude
+                tol = 2.5e-4 if lg else 0.0
+                for i in (2, 3, 4):
+                    assert abs(got[i] - want[i]) <= tol + 1e-6 * abs(want[i]), (i, border, lg, got[i].item(), want[i].item())
+
+
+@pytest.mark.gpu
+def test_radix_select_is_exact_on_given_differences():
+    """Linear de-scaling with value_min 0, value_max 2 makes dh = 2 (pred - gt) exactly: the order statistics of the
+    fused path must equal torch.median / kthvalue of that array BIT for bit (ties, negatives, zeros included)."""
+    g_ = torch.Generator().manual_seed(10)
+    for n_side in (16, 100, 513):
+        gt = torch.rand(1, 1, n_side, n_side, generator=g_) * 0.5
+        d = torch.randn(1, 1, n_side, n_side, generator=g_) * 0.01
+        d[0, 0, :3] = 0.0                                       # ties
+        pred = (gt + d).clamp(0, 1)
+        got = M.tile_scores(pred.cuda(), gt.cuda(), 0.0, 2.0, 0.0, False).cpu()
+        dh = (pred.cuda() * 2.0 + 0.0) - (gt.cuda() * 2.0 + 0.0)
+        assert got[2].item() == torch.median(dh).item()
+        assert got[3].item() == (1.4826 * torch.median((dh - torch.median(dh)).abs())).item()
+        k = 1 + round(0.95 * (dh.numel() - 1))
+        assert got[4].item() == torch.kthvalue(dh.abs().flatten(), k).values.item()
