@@ -165,12 +165,20 @@ int jspsr_pack_weights_multi(const jspsr_pack_desc* descs, int n, long long tota
 /* Inference epilogue (all optional, NULL = absent): out = [relu](acc * scale[c] + bias[c] + addend), the ReLU always
  * last.  With scale/bias from jspsr_bn_fold and addend = the shortcut tensor this is conv -> BatchNorm(eval)
  * (-> + residual) (-> ReLU) of basics.py:49-53,111-123 in one launch.  Not combinable with `stats`. */
+/* Input transform (in_affine, may be NULL): [2][Cin] fp32 (scale | shift), 16-byte aligned.  The gathered tensor is
+ * then read as [relu](in * scale[c] + shift[c]) -- applied between the patch registers and LDS, zero padding stays
+ * zero -- so a conv can consume the RAW output of the preceding conv plus that layer's BatchNorm affine
+ * (jspsr_bn_forward: affine_out) instead of a normalised copy: conv -> BN -> ReLU -> conv of BasicBlock,
+ * basics.py:111-117, without the normalised activation ever existing in memory.  Available where
+ * jspsr_conv2d_in_affine_ok(dtype, Cin, KH, KW, stride) != 0 (the patch kernel: stride 1, 2..9 taps, Cin a multiple
+ * of 32 fp32 / 64 bf16); JSPSR_EINVAL otherwise. */
 int jspsr_conv2d_stats_rows(int B, int OH, int OW);
+int jspsr_conv2d_in_affine_ok(int dtype, int Cin, int KH, int KW, int stride);
 int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const float* bias, void* out,
                          int B, int IH, int IW, int Cin, int in_cstride, int in_coff, int Cout,
                          int out_cstride, int out_coff, int KH, int KW, int stride, int pad, int relu,
                          float* stats, const float* scale, const void* addend, int add_cstride,
-                         jspsr_stream_t stream);
+                         const float* in_affine, int in_relu, jspsr_stream_t stream);
 
 /* gin[b,y,x,c] = bias[c] + sum_{ky,kx,n} gout[b,(y+pad-ky)/stride,(x+pad-kx)/stride,n] * W[n,c,ky,kx]
  * over the taps where the division is exact: the data gradient of the conv above, and equally
@@ -194,12 +202,16 @@ int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const f
  * Conv2d(I->O): G = grad_out, X = input, R = O, C = I.  ConvTranspose2d(I->O, weight (I,O,KH,KW)):
  * G = its input, X = grad of its output, R = I, C = O.
  * workspace: jspsr_conv2d_wgrad_workspace_bytes() bytes (split-K slabs, summed in a fixed order).
+ * x_affine (may be NULL): [2][Cx] (scale | shift) -- X is read as [relu](X * scale + shift), the counterpart of
+ * jspsr_conv2d_forward's in_affine for the weight gradient of a conv whose normalised input was never materialised.
+ * Available where jspsr_conv2d_wgrad_x_affine_ok(...) != 0 (the nine-tap kernel: 3x3, stride 1, pad 1).
  */
 size_t jspsr_conv2d_wgrad_workspace_bytes(int dtype, int B, int OH, int OW, int Cg, int Cx, int KH, int KW);
+int jspsr_conv2d_wgrad_x_affine_ok(int dtype, int B, int OH, int OW, int Cg, int Cx, int KH, int KW, int stride, int pad);
 int jspsr_conv2d_wgrad(int dtype, const void* G, int Cg, int g_cstride, int g_coff, const void* X, int Cx,
                        int x_cstride, int x_coff, float* dW, int R, int C, int B, int OH, int OW,
                        int IH, int IW, int KH, int KW, int stride, int pad, int accumulate,
-                       void* workspace, jspsr_stream_t stream);
+                       const float* x_affine, int x_relu, void* workspace, jspsr_stream_t stream);
 
 /* ---- K4/K5: per-channel operators around the convolutions (HBM-bound, NHWC) -----------------
  * Tensors are (pointer, channel pitch, channel offset) slices of NHWC buffers, `npix` pixels,

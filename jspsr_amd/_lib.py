@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("JSPSR_LAB_LIB") or os.path.join(_HERE, "lib", "libjspsr_hip.so")  # JSPSR_LAB_LIB: kernel-lab builds only
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lock = threading.Lock()
 _lib = None
@@ -40,11 +40,13 @@ SIGNATURES = {
     "jspsr_pack_chunk": (c_i, []),
     "jspsr_pack_weights_multi": (c_i, [c_p, c_i, c_ll, c_p]),
     "jspsr_conv2d_stats_rows": (c_i, [c_i, c_i, c_i]),
-    "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p, c_p, c_p, c_i, c_p]),
+    "jspsr_conv2d_in_affine_ok": (c_i, [c_i] * 5),
+    "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "jspsr_bn_fold": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p]),
     "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p, c_i, c_p, c_p]),
     "jspsr_conv2d_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i] * 8),
-    "jspsr_conv2d_wgrad": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p, c_p]),
+    "jspsr_conv2d_wgrad_x_affine_ok": (c_i, [c_i] * 10),
+    "jspsr_conv2d_wgrad": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p, c_i, c_p, c_p]),
     "jspsr_reduce_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_bn_forward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
                                c_i, c_f, c_p, c_p, c_ll, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),

@@ -523,15 +523,36 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
   }
 
   uint4 preg[P_IT], breg[2][B_IT];
-  auto load_patch = [&](int chunk) {
+  // Input transform (g.in_affine): the gathered tensor is the PRE-normalisation output of a BatchNorm; its per-channel
+  // (scale | shift) and the ReLU are applied here, between the patch registers and LDS, so the normalised activation
+  // never exists in memory (conv -> BN -> ReLU -> conv, basics.py:111-117).  Padding (OOB slots) stays zero.
+  float asc[EPC], ash[EPC];
+  auto load_patch = [&](int chunk) __attribute__((always_inline)) {
     const int soff = chunk * BK * (int)sizeof(T);
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
       const auto v = __builtin_amdgcn_raw_buffer_load_b128(arsrc, poff[i], soff, 0);
       preg[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
+    if (g.in_affine) {
+      const float* ap = g.in_affine + chunk * BK + ch * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + e), b = *reinterpret_cast<const float4*>(ap + g.Cin + e);
+        asc[e] = a.x; asc[e + 1] = a.y; asc[e + 2] = a.z; asc[e + 3] = a.w;
+        ash[e] = b.x; ash[e + 1] = b.y; ash[e + 2] = b.z; ash[e + 3] = b.w;
+      }
+    }
   };
-  auto store_patch = [&]() {
+  auto store_patch = [&]() __attribute__((always_inline)) {
+    if (g.in_affine) {
+      const bool rl = g.in_relu != 0;
+#pragma unroll
+      for (int i = 0; i < P_IT; ++i)
+        if (plds[i] >= 0)
+          *reinterpret_cast<uint4*>(Ps + plds[i]) = poff[i] != OOB ? affine_relu16<T>(preg[i], asc, ash, rl) : make_uint4(0u, 0u, 0u, 0u);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < P_IT; ++i)
       if (plds[i] >= 0) *reinterpret_cast<uint4*>(Ps + plds[i]) = preg[i];
@@ -805,7 +826,7 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
   // unit-stride tap walk, <= 3x3 taps, Cin a multiple of the stage depth: stage the input patch once
   static const int no_patch = [] { const char* e = getenv("JSPSR_CONV_NOPATCH"); return e ? atoi(e) : 0; }();
   constexpr int BKT = NCH * Elem<T>::EPC;
-  if (!no_patch && g.iy_mul == 1 && g.ix_mul == 1 && g.nty >= 1 && g.ntx >= 1 && g.nty <= 3 && g.ntx <= 3 &&
+  if ((!no_patch || g.in_affine) && g.iy_mul == 1 && g.ix_mul == 1 && g.nty >= 1 && g.ntx >= 1 && g.nty <= 3 && g.ntx <= 3 &&
       g.nty * g.ntx > 1 && g.Cin % BKT == 0 && (long long)(g.IW + 20) * 12 * g.in_cstride * (long long)sizeof(T) < 0xE0000000LL) {
     static const int tall = [] { const char* e = getenv("JSPSR_CONV_TALL"); return e ? atoi(e) : 1; }();
     const long long tiles16 = (long long)g.B * ((g.MH + 15) / 16) * ((g.MW + 15) / 16);
@@ -825,6 +846,7 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
     }
     return launch_patch<T, 128, 32, 4, 1>(in, wgt, bias, out, stats, g, s);
   }
+  if (g.in_affine) return fail(JSPSR_EINVAL, "conv2d_forward: in_affine needs the patch kernel (stride 1, 2..9 taps, Cin a multiple of %d): ask jspsr_conv2d_in_affine_ok first", BKT);
   static const int nbuf_env = [] { const char* e = getenv("JSPSR_CONV_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf_narrow = nbuf_env ? nbuf_env : ((long long)g.nty * g.ntx * g.Cin <= 1152 ? 1 : 2);
   if (g.Cout > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(in, wgt, bias, out, stats, g, s);
@@ -934,8 +956,9 @@ extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack
                                     int B, int IH, int IW, int Cin, int in_cstride, int in_coff, int Cout,
                                     int out_cstride, int out_coff, int KH, int KW, int stride, int pad, int relu,
                                     float* stats, const float* scale, const void* addend, int add_cstride,
-                                    jspsr_stream_t stream) {
+                                    const float* in_affine, int in_relu, jspsr_stream_t stream) {
   if (int e = check_common(dtype, in, wpack, out, Cin, in_cstride, in_coff, out_cstride, out_coff, Cout, "conv2d_forward")) return e;
+  if (in_affine && !aligned16(in_affine)) return fail(JSPSR_EALIGN, "conv2d_forward: in_affine must be 16-byte aligned");
   if (addend && add_cstride < Cout) return fail(JSPSR_EINVAL, "conv2d_forward: addend pitch %d < %d channels", add_cstride, Cout);
   if (B <= 0 || IH <= 0 || IW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     return fail(JSPSR_EINVAL, "conv2d_forward: bad geometry");
@@ -954,7 +977,14 @@ extern "C" int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack
   if (stats && (bias || relu || scale || addend))
     return fail(JSPSR_EINVAL, "conv2d_forward: statistics are taken from the raw accumulators (no bias / scale / addend / ReLU)");
   g.scale = scale; g.addend = addend; g.add_cstride = add_cstride;
+  g.in_affine = in_affine; g.in_relu = in_relu;
   return dtype == JSPSR_F32 ? launch<float>(in, wpack, bias, out, stats, g, s) : launch<__bf16>(in, wpack, bias, out, stats, g, s);
+}
+
+extern "C" int jspsr_conv2d_in_affine_ok(int dtype, int Cin, int KH, int KW, int stride) {
+  const int bk = NCH * (dtype == JSPSR_F32 ? 4 : 8);
+  return (dtype == JSPSR_F32 || dtype == JSPSR_BF16) && stride == 1 && KH >= 1 && KW >= 1 && KH <= 3 && KW <= 3 && KH * KW > 1 &&
+         Cin > 0 && Cin % bk == 0;
 }
 
 extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,

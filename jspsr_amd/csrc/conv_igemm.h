@@ -47,6 +47,38 @@ struct ConvGeom {
   const void* addend;     // optional tensor on the written grid: out = [relu](acc * scale + bias + addend)
   int add_cstride;        // its channel pitch (channel 0 of the addend = channel out_coff of the written slice)
   const float* scale;     // optional per-output-channel factor (inference: BatchNorm folded into the epilogue)
+  const float* in_affine; // optional [2][Cin] (scale | shift): the gathered tensor is read as [relu](x * scale + shift),
+  int in_relu;            // applied while the patch is staged (patch kernel only); zero padding stays zero
 };
 
 }  // namespace jspsr
+
+// [relu](x * sc + sh) on 16 bytes of T (4 fp32 / 8 bf16 channels), fp32 arithmetic, one rounding to the storage type
+template <typename T, int N>
+__device__ __forceinline__ uint4 affine_relu16(const uint4& v, const float (&sc)[N], const float (&sh)[N], bool relu) {
+  static_assert(N * sizeof(T) == 16, "one 16-byte chunk of channels");
+  uint4 r;
+  if constexpr (sizeof(T) == 4) {
+    float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[i] = f[i] * sc[i] + sh[i];
+      if (relu) f[i] = fmaxf(f[i], 0.f);
+    }
+    r = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  } else {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float lo = __uint_as_float(w[i] << 16) * sc[2 * i] + sh[2 * i];
+      float hi = __uint_as_float(w[i] & 0xffff0000u) * sc[2 * i + 1] + sh[2 * i + 1];
+      if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+      const __bf16 bl = (__bf16)lo, bh = (__bf16)hi;
+      o[i] = (unsigned)__builtin_bit_cast(unsigned short, bl) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+    }
+    r = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  return r;
+}
+

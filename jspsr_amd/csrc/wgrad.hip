@@ -281,6 +281,8 @@ struct PatchGeom {
   int strips_x;             // W / U
   int rows_per_blk, row_blks;
   int pairs_g, pairs_x;     // tiles of G channels / chunks of X channels
+  const float* x_affine;    // optional [2][Cx] (scale | shift): X is read as [relu](x * scale + shift) while it is staged
+  int x_relu;               // (the conv's input was never materialised: see conv.hip, in_affine); padding stays zero
 };
 
 template <typename T> struct WP;
@@ -334,6 +336,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
   const unsigned g_rowb = (unsigned)(g.W * g_pix), x_rowb = (unsigned)(g.W * x_pix);
 
   uint4 greg[2][G_IT], xreg[2][X_IT];
+  float xsc[EPC], xsh[EPC];                                    // this thread's channel chunk never changes
+  if (g.x_affine && x_ok) {
+    const float* ap = g.x_affine + cx0 + ch * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + e), b2 = *reinterpret_cast<const float4*>(ap + g.Cx + e);
+      xsc[e] = a.x; xsc[e + 1] = a.y; xsc[e + 2] = a.z; xsc[e + 3] = a.w;
+      xsh[e] = b2.x; xsh[e + 1] = b2.y; xsh[e + 2] = b2.z; xsh[e + 3] = b2.w;
+    }
+  }
   auto load_g = [&](auto SET, int oy) {
     constexpr int set = decltype(SET)::value;
     const bool ok = oy < y1;                                   // uniform
@@ -361,12 +373,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < G_IT; ++i) *reinterpret_cast<uint4*>(g_st + buf * GS_BYTES + i * RSTEP * P) = greg[set][i];
   };
-  auto store_x = [&](auto SET, int slot) {
+  auto store_x = [&](auto SET, int slot, int iy) {           // iy: the input row the register set holds
     constexpr int set = decltype(SET)::value;
+    const bool tr = g.x_affine != nullptr, rowok = (unsigned)iy < (unsigned)g.H, rl = g.x_relu != 0;
 #pragma unroll
     for (int i = 0; i < X_IT; ++i)
-      if ((X_IT * RSTEP <= U + 2) || r0 + i * RSTEP < U + 2)
-        *reinterpret_cast<uint4*>(x_st + slot * XS_BYTES + i * RSTEP * P) = xreg[set][i];
+      if ((X_IT * RSTEP <= U + 2) || r0 + i * RSTEP < U + 2) {
+        uint4 v = xreg[set][i];
+        if (tr) v = (rowok && xcol[i] != OOB) ? affine_relu16<T>(v, xsc, xsh, rl) : make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(x_st + slot * XS_BYTES + i * RSTEP * P) = v;
+      }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -443,14 +459,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
   // (G row oy, X row oy+1) pairs.  Steps are branch-free (rows past the range load as zeros, unused).
   load_x(S0{}, y0 - 1);
   load_x(S1{}, y0);
-  store_x(S0{}, (y0 + 0) & 3);
-  store_x(S1{}, (y0 + 1) & 3);
+  store_x(S0{}, (y0 + 0) & 3, y0 - 1);
+  store_x(S1{}, (y0 + 1) & 3, y0);
   load_g(S0{}, y0);
   load_x(S0{}, y0 + 1);
   load_g(S1{}, y0 + 1);
   load_x(S1{}, y0 + 2);
   store_g(S0{}, 0);
-  store_x(S0{}, (y0 + 2) & 3);
+  store_x(S0{}, (y0 + 2) & 3, y0 + 1);
   __syncthreads();
   // step for row oy (stage parity CUR): loads of row oy+2 -> MFMAs of row oy -> row oy+1 regs -> LDS -> barrier
   auto step = [&](auto CUR, auto NXT, int oy) {
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
     load_x(CUR, oy + 3);
     compute(cur, oy);
     store_g(NXT, cur ^ 1);
-    store_x(NXT, (oy + 3) & 3);
+    store_x(NXT, (oy + 3) & 3, oy + 2);
     __syncthreads();
   };
   int oy = y0;
@@ -589,7 +605,8 @@ int launch_w(const void* G, const void* X, float* ws, const WgradGeom& g, int sp
 }
 
 template <typename T>
-int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradGeom& g, int accumulate, hipStream_t s) {
+int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradGeom& g, int accumulate, hipStream_t s,
+        const float* x_affine, int x_relu) {
   if (g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad == 1 && g.IH == g.OH && g.IW == g.OW && wgrad_patch_enabled()) {
     const PatchPlan pp = make_patch_plan<T>(g.B, g.OH, g.OW, g.Cg, g.Cx);
     const long long img_g = (long long)g.OH * g.OW * g.g_cs * (long long)sizeof(T);
@@ -602,6 +619,7 @@ int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradG
       q.Ktot = g.Ktot; q.strips_x = g.OW / WP<T>::U;
       q.rows_per_blk = pp.rows_per_blk; q.row_blks = pp.row_blks;
       q.pairs_g = (g.Cg + 63) / 64; q.pairs_x = (g.Cx + 63) / 64;
+      q.x_affine = x_affine; q.x_relu = x_relu;
       const long long nblk = (long long)pp.units * q.pairs_g * q.pairs_x;
       hipLaunchKernelGGL(wgrad_patch_kernel<T>, dim3((unsigned)nblk), dim3(NT), 0, s, static_cast<const T*>(G),
                          static_cast<const T*>(X), ws, q);
@@ -613,6 +631,7 @@ int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradG
       return check_launch("conv2d_wgrad_reduce");
     }
   }
+  if (x_affine) return fail(JSPSR_EINVAL, "conv2d_wgrad: x_affine needs the nine-tap kernel (3x3, stride 1, pad 1): ask jspsr_conv2d_wgrad_x_affine_ok first");
   const Plan p = make_plan<T>(g.M, g.Cg, g.Ktot);
   g.m_per_split = p.m_per_split;
   // 32-bit buffer offsets: one slice of G, and the images of X one slice touches, must stay < 3.75 GiB
@@ -651,8 +670,9 @@ extern "C" size_t jspsr_conv2d_wgrad_workspace_bytes(int dtype, int B, int OH, i
 extern "C" int jspsr_conv2d_wgrad(int dtype, const void* G, int Cg, int g_cstride, int g_coff, const void* X, int Cx,
                                   int x_cstride, int x_coff, float* dW, int R, int C, int B, int OH, int OW,
                                   int IH, int IW, int KH, int KW, int stride, int pad, int accumulate,
-                                  void* workspace, jspsr_stream_t stream) {
+                                  const float* x_affine, int x_relu, void* workspace, jspsr_stream_t stream) {
   if (dtype != JSPSR_F32 && dtype != JSPSR_BF16) return fail(JSPSR_EINVAL, "conv2d_wgrad: bad dtype");
+  if (x_affine && !aligned16(x_affine)) return fail(JSPSR_EALIGN, "conv2d_wgrad: x_affine must be 16-byte aligned");
   if (!G || !X || !dW || !workspace) return fail(JSPSR_EINVAL, "conv2d_wgrad: null pointer");
   const int epc = dtype == JSPSR_F32 ? 4 : 8;
   if (Cg <= 0 || Cx <= 0 || Cg % epc || Cx % epc || g_cstride % epc || g_coff % epc || x_cstride % epc || x_coff % epc ||
@@ -669,6 +689,13 @@ extern "C" int jspsr_conv2d_wgrad(int dtype, const void* G, int Cg, int g_cstrid
   g.M = (long long)B * OH * OW;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
-  return dtype == JSPSR_F32 ? run<float>(G, X, dW, R, C, ws, g, accumulate, s)
-                            : run<__bf16>(G, X, dW, R, C, ws, g, accumulate, s);
+  return dtype == JSPSR_F32 ? run<float>(G, X, dW, R, C, ws, g, accumulate, s, x_affine, x_relu)
+                            : run<__bf16>(G, X, dW, R, C, ws, g, accumulate, s, x_affine, x_relu);
+}
+
+extern "C" int jspsr_conv2d_wgrad_x_affine_ok(int dtype, int B, int OH, int OW, int Cg, int Cx, int KH, int KW, int stride, int pad) {
+  if ((dtype != JSPSR_F32 && dtype != JSPSR_BF16) || KH != 3 || KW != 3 || stride != 1 || pad != 1 || !wgrad_patch_enabled()) return 0;
+  const PatchPlan pp = dtype == JSPSR_BF16 ? make_patch_plan<__bf16>(B, OH, OW, Cg, Cx) : make_patch_plan<float>(B, OH, OW, Cg, Cx);
+  const long long es = dtype == JSPSR_BF16 ? 2 : 4;
+  return pp.ok && (long long)OH * OW * Cg * es < 0xF0000000LL && (long long)OH * OW * Cx * es < 0xF0000000LL;
 }

@@ -77,8 +77,17 @@ def pack_weight(w: torch.Tensor, mode: int, c_pad: int, dtype: torch.dtype) -> t
     return out
 
 
+def fused_input_ok(dtype, B, OH, OW, Cin, Cout, KH, KW, stride, pad) -> bool:
+    """Can a conv with this geometry read its input through (scale | shift) + ReLU -- in the forward (in_affine) AND in
+    its weight gradient (x_affine)?  (The patch kernels: 3x3, stride 1, pad 1, Cin a multiple of 32 fp32 / 64 bf16.)"""
+    lib = _lib.load()
+    dt = F32 if dtype == torch.float32 else BF16
+    return bool(lib.jspsr_conv2d_in_affine_ok(dt, Cin, KH, KW, stride)) and \
+        bool(lib.jspsr_conv2d_wgrad_x_affine_ok(dt, B, OH, OW, Cout, Cin, KH, KW, stride, pad))
+
+
 def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0, cin=None, in_coff=0, stats=False,
-                   scale=None, addend=None):
+                   scale=None, addend=None, in_affine=None, in_relu=False):
     """x (B,IH,IW,Cs) NHWC, wpack [Cout][KH][KW][Cin] -> (B,OH,OW,Cout) (or a slice of `out`).
     stats=True (no bias / ReLU): also returns the BatchNorm partial statistics (rows, 2, Cout) fp32 taken from
     the accumulators in the epilogue.  scale (Cout,) fp32 / addend (B,OH,OW,Cout): inference epilogue
@@ -108,6 +117,7 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
                                         scale.data_ptr() if scale is not None else None,
                                         addend.data_ptr() if addend is not None else None,
                                         pitch(addend) if addend is not None else 0,
+                                        in_affine.data_ptr() if in_affine is not None else None, int(in_relu),
                                         _stream()), "jspsr_conv2d_forward")
     return (out, st) if stats else out
 
@@ -139,7 +149,8 @@ def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None
     return out
 
 
-def conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=None, accumulate=False, g_coff=0, cg=None, x_coff=0, cx=None):
+def conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=None, accumulate=False, g_coff=0, cg=None, x_coff=0, cx=None,
+                 x_affine=None, x_relu=False):
     """dW (R,C,KH,KW) fp32 = sum_pixels G[.., r] * X[shifted.., c].  G (B,OH,OW,Cgs), X (B,IH,IW,Cxs) NHWC."""
     _chk_s(G, "conv2d_wgrad")
     _chk_s(X, "conv2d_wgrad")
@@ -156,7 +167,8 @@ def conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=None, accumulate=False, g_
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=G.device)
     _lib.check(lib.jspsr_conv2d_wgrad(dt, G.data_ptr(), cg, Cgs, g_coff, X.data_ptr(), cx, Cxs, x_coff,
                                       out.data_ptr(), R, C, B, OH, OW, IH, IW, KH, KW, stride, pad,
-                                      int(accumulate), ws.data_ptr(), _stream()), "jspsr_conv2d_wgrad")
+                                      int(accumulate), x_affine.data_ptr() if x_affine is not None else None, int(x_relu),
+                                      ws.data_ptr(), _stream()), "jspsr_conv2d_wgrad")
     return out
 
 

@@ -427,7 +427,7 @@ def pad_channels(x: torch.Tensor, mult: int) -> torch.Tensor:
     return x if p == 0 else torch.nn.functional.pad(x, (0, p))
 
 
-def _wgrad_into(param, G, X, R, C, KH, KW, stride, pad):
+def _wgrad_into(param, G, X, R, C, KH, KW, stride, pad, **kw):
     """Weight gradient of one conv.  If the parameter's .grad lives in a GradReducer's flat buffer (opted in through
     `_jspsr_direct_grad`), the ordered slab reduction adds straight into it and the autograd node reports no
     gradient for that input -- the per-parameter `grad += dW` pass disappears; the reducer's bucket bookkeeping is
@@ -435,12 +435,12 @@ def _wgrad_into(param, G, X, R, C, KH, KW, stride, pad):
     gbuf = param.grad if param is not None and getattr(param, "_jspsr_direct_grad", False) else None
     if (gbuf is not None and gbuf.dtype == torch.float32 and gbuf.is_contiguous() and gbuf.is_cuda
             and tuple(gbuf.shape) == (R, C, KH, KW)):
-        K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=gbuf, accumulate=True)
+        K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=gbuf, accumulate=True, **kw)
         ready = getattr(param, "_jspsr_grad_ready", None)
         if ready is not None:
             ready(param)
         return None
-    return K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad)
+    return K.conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, **kw)
 
 
 # ---- weight gradients beside the data-gradient chain -------------------------------------------------------------
@@ -458,16 +458,19 @@ def aux_streams():
     return list(_aux_streams.values())
 
 
-def _wgrad_async(param, G, X, R, C, KH, KW, stride, pad):
+def _wgrad_async(param, G, X, R, C, KH, KW, stride, pad, **kw):
     if not wgrad_async:
-        return _wgrad_into(param, G, X, R, C, KH, KW, stride, pad)
+        return _wgrad_into(param, G, X, R, C, KH, KW, stride, pad, **kw)
     cur = torch.cuda.current_stream()
     aux = _aux_streams.get(cur.cuda_stream)
     if aux is None:
         aux = _aux_streams[cur.cuda_stream] = torch.cuda.Stream(device=G.device)
     aux.wait_stream(cur)                     # G and X are complete on the home stream
     with torch.cuda.stream(aux):
-        dW = _wgrad_into(param, G, X, R, C, KH, KW, stride, pad)
+        dW = _wgrad_into(param, G, X, R, C, KH, KW, stride, pad, **kw)
+    for t_ in kw.values():
+        if isinstance(t_, torch.Tensor):
+            t_.record_stream(aux)
     G.record_stream(aux)                     # home-pool tensors read by queued aux work
     X.record_stream(aux)
     # Run-ahead throttle.  A block released while another stream still has work queued is handed out again only after
@@ -696,6 +699,11 @@ def batch_norm(x, gamma, beta, running_mean, running_var, momentum, eps, trainin
 
 
 fold_shortcut_bn = os.environ.get("JSPSR_BN_FOLD_SHORTCUT", "1") != "0"   # A/B switch (Switches)
+# conv1 -> bn1 -> ReLU -> conv2 of a BasicBlock without the normalised activation: conv2 (and its weight gradient) read
+# conv1's RAW output and apply bn1's (scale | shift) + ReLU while staging their operand (jspsr_conv2d_forward: in_affine,
+# jspsr_conv2d_wgrad: x_affine).  Where the patch kernels do not apply (channel counts not a multiple of 32 / 64) the
+# block falls back to the separate BatchNorm pass.
+fuse_bn1_input = os.environ.get("JSPSR_FUSE_BN1", "1") != "0"
 
 
 class _ResUnit(torch.autograd.Function):
@@ -724,14 +732,22 @@ class _ResUnit(torch.autograd.Function):
         g1d, b1d, g2d, b2d = g1.detach(), b1.detach(), g2.detach(), b2.detach()
 
         def conv_bn(inp, wt, k, st, pad, gam, bet, rm, rv, mom, eps, tr, relu, res=None, rs=1.0, out=None, par=None,
-                    res_affine=None, stats_only=False):
-            z = K.conv2d_forward(inp, _packed(par, wt, 0, inp.shape[3], cdt), None, st, pad, False, stats=tr)
+                    res_affine=None, stats_only=False, in_affine=None):
+            z = K.conv2d_forward(inp, _packed(par, wt, 0, inp.shape[3], cdt), None, st, pad, False, stats=tr,
+                                 in_affine=in_affine, in_relu=in_affine is not None)
             z, part = z if tr else (z, None)
             y, mean, invstd = K.bn_forward(z, gam, bet, rm, rv, mom, eps, tr, relu, res, rs, partial=part, out=out,
                                            res_affine=res_affine, stats_only=stats_only)
             return z, y, mean, invstd
 
-        z1, y1, m1, i1 = conv_bn(x, w1d, 3, stride, 1, g1d, b1d, rm1, rv1, mom1, eps1, tr1, True, par=w1)
+        OH1, OW1 = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        fuse1 = fuse_bn1_input and K.fused_input_ok(cdt, B, OH1, OW1, O, O, 3, 3, 1, 1)
+        if fuse1:    # statistics + (scale | shift) of bn1 only: relu(bn1(z1)) is formed inside conv2's / wgrad2's staging
+            z1, aff1, m1, i1 = conv_bn(x, w1d, 3, stride, 1, g1d, b1d, rm1, rv1, mom1, eps1, tr1, True, par=w1, stats_only=True)
+            y1 = None
+        else:
+            z1, y1, m1, i1 = conv_bn(x, w1d, 3, stride, 1, g1d, b1d, rm1, rv1, mom1, eps1, tr1, True, par=w1)
+            aff1 = None
         if has_d:
             rmd, rvd, momd, epsd, trd = bns[2]
             wdd, gdd, bdd = wd.detach().contiguous(), gd.detach(), bd.detach()
@@ -751,19 +767,19 @@ class _ResUnit(torch.autograd.Function):
             trd = False
             r = x
         out_v = dest[0].slice(dest[1], O, z1.shape[:3]) if dest is not None else None
-        z2, out, m2, i2 = conv_bn(y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale), out_v, par=w2,
-                                  res_affine=r_aff)
+        z2, out, m2, i2 = conv_bn(z1 if fuse1 else y1, w2d, 3, 1, 1, g2d, b2d, rm2, rv2, mom2, eps2, tr2, bool(act), r, float(scale),
+                                  out_v, par=w2, res_affine=r_aff, in_affine=aff1)
         ctx.cfg = (stride, float(scale), bool(act), has_d, tr1, tr2, trd)
         ctx.wparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (w1, w2, wd))
         ctx.bparams = tuple(p if isinstance(p, torch.nn.Parameter) else None for p in (g1, b1, g2, b2, gd, bd))
         ctx.save_for_backward(x, w1d, g1d, b1d, z1, m1, i1, y1, w2d, g2d, b2d, z2, m2, i2, out if act else None,
-                              wdd, gdd, bdd, zd, md, idd)
+                              wdd, gdd, bdd, zd, md, idd, aff1)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         stride, scale, act, has_d, tr1, tr2, trd = ctx.cfg
-        (x, w1, g1, b1, z1, m1, i1, y1, w2, g2, b2, z2, m2, i2, out, wd, gd, bd, zd, md, idd) = ctx.saved_tensors
+        (x, w1, g1, b1, z1, m1, i1, y1, w2, g2, b2, z2, m2, i2, out, wd, gd, bd, zd, md, idd, aff1) = ctx.saved_tensors
         cdt = x.dtype
         B, H, W, Cin = x.shape
         O = w1.shape[0]
@@ -779,8 +795,11 @@ class _ResUnit(torch.autograd.Function):
         if dres is None:
             dres = dout
         p1, p2, pd = ctx.wparams
-        dW2 = _wgrad_async(p2, dz2, y1, O, O, 3, 3, 1, 1)
-        dy1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), y1.shape[1:3], 1, 1)
+        if aff1 is not None:      # conv2's input was never materialised: its weight gradient re-forms relu(bn1(z1)) while staging
+            dW2 = _wgrad_async(p2, dz2, z1, O, O, 3, 3, 1, 1, x_affine=aff1, x_relu=True)
+        else:
+            dW2 = _wgrad_async(p2, dz2, y1, O, O, 3, 3, 1, 1)
+        dy1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), z1.shape[1:3], 1, 1)
         del dz2
         dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1, grads_into=sink1)
         if sink1 is not None:

@@ -395,3 +395,56 @@ def test_packed_weight_cache_and_single_launch_repack():
         params[0].add_(1.0)                        # an ordinary in-place update: seen through the version counter
     c = ops._packed(params[0], params[0].detach(), 0, 16, torch.bfloat16)
     assert torch.equal(c, K.pack_weight(params[0].detach(), 0, 16, torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,O", [(2, 24, 64, 64, 64), (1, 19, 128, 128, 64), (2, 16, 64, 64, 128)])   # W: a multiple of the nine-tap wgrad kernel's 64-pixel strips
+def test_input_affine_relu_in_conv_and_wgrad_staging(B, H, W, C, O, dtype):
+    """jspsr_conv2d_forward(in_affine) / jspsr_conv2d_wgrad(x_affine): the conv reads relu(x * scale + shift) formed
+    between the patch registers and LDS.  Against the same kernels fed with the materialised tensor (what a separate
+    BatchNorm pass would have stored): equal up to the rounding of that tensor -- the kernel forms x * scale + shift
+    with one fused multiply-add, torch with two roundings, and in bf16 the stored copy can land on the neighbouring
+    value -- i.e. relative L2 < 1e-6 (fp32) / 2e-3 (bf16).  Zero padding must stay zero (a shift > 0 would otherwise leak
+    relu(shift) into the border: checked separately on a constant-zero input, exactly)."""
+    K = _k()
+    g_ = torch.Generator().manual_seed(B * 7 + H + C + O)
+    x = torch.randn(B, H, W, C, generator=g_).cuda().to(dtype)
+    aff = torch.stack((1 + 0.3 * torch.randn(C, generator=g_), 0.2 + 0.3 * torch.randn(C, generator=g_))).cuda().contiguous()
+    w = (torch.randn(O, C, 3, 3, generator=g_) / (C * 9) ** 0.5).cuda()
+    go = torch.randn(B, H, W, O, generator=g_).cuda().to(dtype)
+    assert K.fused_input_ok(dtype, B, H, W, C, O, 3, 3, 1, 1)
+    tol = 1e-6 if dtype == torch.float32 else 2e-3
+    rel = lambda p_, q_: ((p_.double() - q_.double()).norm() / q_.double().norm()).item()
+    y_mat = torch.relu(x.float() * aff[0] + aff[1]).to(dtype)
+    wp = K.pack_weight(w, 0, C, dtype)
+    a = K.conv2d_forward(x, wp, None, 1, 1, in_affine=aff, in_relu=True)
+    b = K.conv2d_forward(y_mat, wp, None, 1, 1)
+    assert rel(a, b) < tol
+    a_s, st_a = K.conv2d_forward(x, wp, None, 1, 1, stats=True, in_affine=aff, in_relu=True)
+    assert torch.equal(a_s, a) and rel(st_a, K.conv2d_forward(y_mat, wp, None, 1, 1, stats=True)[1]) < 10 * tol
+    da = K.conv2d_wgrad(go, x, O, C, 3, 3, 1, 1, x_affine=aff, x_relu=True)
+    db = K.conv2d_wgrad(go, y_mat, O, C, 3, 3, 1, 1)
+    assert rel(da, db) < tol
+    y_lin = (x.float() * aff[0] + aff[1]).to(dtype)                          # without the ReLU
+    assert rel(K.conv2d_forward(x, wp, None, 1, 1, in_affine=aff, in_relu=False), K.conv2d_forward(y_lin, wp, None, 1, 1)) < tol
+    # padding: x = 0, scale = 1, shift = 0.5 => the transformed input is 0.5 inside the raster and 0 (not 0.5) outside:
+    # the conv of ones-weights counts the in-raster taps, exactly
+    zero = torch.zeros(1, 8, 64, C, device="cuda", dtype=dtype)
+    half = torch.stack((torch.ones(C), torch.full((C,), 0.5))).cuda().contiguous()
+    ones_w = K.pack_weight(torch.ones(O, C, 3, 3, device="cuda"), 0, C, dtype)
+    cnt = K.conv2d_forward(zero, ones_w, None, 1, 1, in_affine=half, in_relu=True).float()
+    taps = torch.nn.functional.conv2d(torch.ones(1, 1, 8, 64), torch.ones(1, 1, 3, 3), padding=1)[0, 0].cuda()
+    assert torch.equal(cnt[0, :, :, 0], taps * 0.5 * C)
+    dcnt = K.conv2d_wgrad(torch.ones(1, 8, 64, O, device="cuda", dtype=dtype), zero, O, C, 3, 3, 1, 1, x_affine=half, x_relu=True)
+    want = torch.tensor([[7 * 63, 7 * 64, 7 * 63], [8 * 63, 8 * 64, 8 * 63], [7 * 63, 7 * 64, 7 * 63]], dtype=torch.float32).cuda() * 0.5
+    assert torch.equal(dcnt[0, 0], want)
+
+
+def test_input_affine_is_refused_where_no_kernel_applies_it():
+    K = _k()
+    from jspsr_amd._lib import JspsrHipError
+    x = torch.randn(1, 8, 8, 16, device="cuda")
+    aff = torch.ones(2, 16, device="cuda")
+    assert not K.fused_input_ok(torch.float32, 1, 8, 8, 16, 16, 3, 3, 1, 1)
+    with pytest.raises(JspsrHipError, match="in_affine"):
+        K.conv2d_forward(x, K.pack_weight(torch.randn(16, 16, 3, 3, device="cuda"), 0, 16, torch.float32), None, 1, 1, in_affine=aff)
