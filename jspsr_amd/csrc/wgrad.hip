@@ -289,7 +289,10 @@ template <typename T> struct WP;
 template <> struct WP<float> { static constexpr int U = 32; };
 template <> struct WP<__bf16> { static constexpr int U = 64; };
 
-template <typename T>
+// XAFF: X is read through x_affine (+ ReLU) while it is staged -- a separate instantiation, so the plain kernel keeps
+// its register allocation (with the transform compiled in, the bf16 kernel sits at the 256-VGPR limit: every launch
+// measured 13 % slower, transform used or not)
+template <typename T, bool XAFF>
 __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict__ G, const T* __restrict__ X,
                                                            float* __restrict__ ws, PatchGeom g) {
   constexpr int EPC = WT<T>::EPC, U = WP<T>::U, TC = 64;      // 64-channel tiles on both sides
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
 
   uint4 greg[2][G_IT], xreg[2][X_IT];
   float xsc[EPC], xsh[EPC];                                    // this thread's channel chunk never changes
-  if (g.x_affine && x_ok) {
+  if (XAFF && x_ok) {
     const float* ap = g.x_affine + cx0 + ch * EPC;
 #pragma unroll
     for (int e = 0; e < EPC; e += 4) {
@@ -375,12 +378,12 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
   };
   auto store_x = [&](auto SET, int slot, int iy) {           // iy: the input row the register set holds
     constexpr int set = decltype(SET)::value;
-    const bool tr = g.x_affine != nullptr, rowok = (unsigned)iy < (unsigned)g.H, rl = g.x_relu != 0;
+    const bool rowok = (unsigned)iy < (unsigned)g.H, rl = g.x_relu != 0;
 #pragma unroll
     for (int i = 0; i < X_IT; ++i)
       if ((X_IT * RSTEP <= U + 2) || r0 + i * RSTEP < U + 2) {
         uint4 v = xreg[set][i];
-        if (tr) v = (rowok && xcol[i] != OOB) ? affine_relu16<T>(v, xsc, xsh, rl) : make_uint4(0u, 0u, 0u, 0u);
+        if (XAFF) v = (rowok && xcol[i] != OOB) ? affine_relu16<T>(v, xsc, xsh, rl) : make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(x_st + slot * XS_BYTES + i * RSTEP * P) = v;
       }
   };
@@ -621,8 +624,12 @@ int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradG
       q.pairs_g = (g.Cg + 63) / 64; q.pairs_x = (g.Cx + 63) / 64;
       q.x_affine = x_affine; q.x_relu = x_relu;
       const long long nblk = (long long)pp.units * q.pairs_g * q.pairs_x;
-      hipLaunchKernelGGL(wgrad_patch_kernel<T>, dim3((unsigned)nblk), dim3(NT), 0, s, static_cast<const T*>(G),
-                         static_cast<const T*>(X), ws, q);
+      if (x_affine)
+        hipLaunchKernelGGL((wgrad_patch_kernel<T, true>), dim3((unsigned)nblk), dim3(NT), 0, s, static_cast<const T*>(G),
+                           static_cast<const T*>(X), ws, q);
+      else
+        hipLaunchKernelGGL((wgrad_patch_kernel<T, false>), dim3((unsigned)nblk), dim3(NT), 0, s, static_cast<const T*>(G),
+                           static_cast<const T*>(X), ws, q);
       if (int e = check_launch("conv2d_wgrad_patch")) return e;
       const long long total = (long long)R * g.Ktot;
       const int blocks = (int)((total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096);
