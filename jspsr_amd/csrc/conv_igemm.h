@@ -51,6 +51,11 @@ struct ConvGeom {
   int in_relu;            // applied while the patch is staged (patch kernel only); zero padding stays zero
 };
 
+// K2r (conv64.hip): 3x3 64->64 unit-stride bf16 conv / data gradient, weights resident in registers
+bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const void* out);
+int launch_conv64_resident(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g,
+                           hipStream_t s);
+
 }  // namespace jspsr
 
 // [relu](x * sc + sh) on 16 bytes of T (4 fp32 / 8 bf16 channels), fp32 arithmetic, one rounding to the storage type

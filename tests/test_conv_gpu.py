@@ -142,6 +142,56 @@ def test_conv_16x16_tile_path(dtype, B, H, W, Cin, Cout):
     assert _relerr(_nchw(dx.float()), xx.grad) < tol
 
 
+@pytest.mark.parametrize("B,H,W", [(4, 256, 256), (5, 232, 250), (1, 512, 520)])
+def test_conv_resident_weights_path(B, H, W):
+    """3x3 64->64 bf16 convs on >= 1024 16x16 tiles run K2r (conv64.hip: weights in registers, patches by LDS-DMA,
+    zero padding from the descriptor's range check): forward with the BatchNorm partial statistics on ragged rasters,
+    every epilogue form (bias + ReLU; scale + addend + ReLU), channel slices on both sides, and the data gradient
+    (reversed tap walk) with an addend."""
+    K = _k()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 64, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    wp = K.pack_weight(w.cuda(), 0, 64, dtype)
+    xd = _nhwc(x).to(dtype)
+    y, st = K.conv2d_forward(xd, wp, None, 1, 1, stats=True)
+    assert _relerr(_nchw(y.float()), ref) < 6e-3
+    # border pixels alone (zero padding) and interior alone
+    edge = torch.zeros(H, W, dtype=torch.bool)
+    edge[0] = edge[-1] = True
+    edge[:, 0] = edge[:, -1] = True
+    assert _relerr(_nchw(y.float())[..., edge], ref[..., edge]) < 6e-3
+    tot = st.double().sum(0).cpu()
+    assert _relerr(tot[0], ref.sum((0, 2, 3))) < 1e-4 and _relerr(tot[1], (ref * ref).sum((0, 2, 3))) < 1e-5
+    # statistics rows are numbered by 8x16 tiles: each row holds exactly its own pixels
+    rows = st.double().cpu().reshape(B, (H + 7) // 8, (W + 15) // 16, 2, 64)
+    r8 = F.pad(ref, (0, -W % 16, 0, -H % 8)).reshape(B, 64, (H + 7) // 8, 8, (W + 15) // 16, 16).sum((3, 5)).permute(0, 2, 3, 1)
+    assert (rows[..., 0, :] - r8).abs().max() < 1e-3 * r8.abs().max()
+    # bias + ReLU
+    bias = torch.randn(64, generator=g)
+    y2 = K.conv2d_forward(xd, wp, bias.cuda(), 1, 1, relu=True)
+    assert _relerr(_nchw(y2.float()), F.relu(ref + bias.double().view(1, -1, 1, 1))) < 6e-3
+    # scale + bias + addend + ReLU, reading a channel slice of a wider tensor and writing into a slice of a wider one
+    scale = torch.rand(64, generator=g) + 0.5
+    res = torch.randn(B, 64, H, W, generator=g).bfloat16().float()
+    wide = torch.randn(B, H, W, 160, generator=g).bfloat16().cuda()
+    wide[..., 32:96] = xd
+    out = torch.full((B, H, W, 128), 7.0, dtype=dtype, device="cuda")
+    K.conv2d_forward(wide, wp, bias.cuda(), 1, 1, relu=True, out=out, out_coff=64, cin=64, in_coff=32, scale=scale.cuda(),
+                     addend=_nhwc(res).to(dtype))
+    ref3 = F.relu((ref * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1)).bfloat16().double() + res.double())
+    assert _relerr(_nchw(out[..., 64:].float()), ref3) < 6e-3
+    assert (out[..., :64] == 7.0).all()
+    # data gradient with an addend
+    go = torch.randn(B, 64, H, W, generator=g).bfloat16().float()
+    xx = torch.zeros(B, 64, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xx, w.double(), None, 1, 1).backward(go.double())
+    dx = K.conv2d_dgrad(_nhwc(go).to(dtype), K.pack_weight(w.cuda(), 1, 64, dtype), (H, W), 1, 1, addend=_nhwc(res).to(dtype))
+    assert _relerr(_nchw(dx.float()), xx.grad.bfloat16().double() + res.double()) < 6e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [
     (2, 64, 64, 64, 64),      # one tile pair
@@ -331,10 +381,10 @@ def test_conv_epilogue_statistics(dtype, B, H, W, Cin, Cout, k, stride, pad):
 
 
 @pytest.mark.parametrize("env", [{"JSPSR_CONV_TALL": "2"}, {"JSPSR_CONV_NOPATCH": "1"}, {"JSPSR_WGRAD_NOPATCH": "1"},
-                                 {"JSPSR_CONV_TALL": "0"}])
+                                 {"JSPSR_CONV_TALL": "0"}, {"JSPSR_CONV_RESIDENT": "0"}])
 def test_opt_in_kernel_variants_in_a_child_process(env):
     """The library reads its lab switches once per process: the opt-in / fallback instantiations (8-wave 256x128 tile,
-    generic implicit-GEMM kernel only, generic weight-gradient kernel only, no 16x16 tile) are exercised in a child
+    generic implicit-GEMM kernel only, generic weight-gradient kernel only, no 16x16 tile, no register-resident 64-channel kernel) are exercised in a child
     process against the same fp64 reference, so that they stay correct while they are not the default."""
     import subprocess
     import sys
