@@ -6,15 +6,18 @@
 // parked on the stage barrier / weight vmcnt).  Here a PERSISTENT workgroup per CU (8 waves = 4 pixel groups x 2
 // channel groups, each wave 64 pixels x 32 channels) loads its 32 weight rows ONCE into 144 VGPRs (36 MFMA B
 // fragments) and walks tiles of 16x16 pixels:
-//   * the 18x18-pixel input patch of tile t+1 arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 41 one-KiB pieces) into the
+//   * the 18x18-pixel input patch of tile t+1 arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 47 pieces of 7 pixels) into the
 //     second patch buffer while tile t is multiplied -- no staging registers, no ds_write pass, no cold prologue;
-//   * LDS image: pixel-major 128-byte rows, 16-byte chunk c of pixel P at chunk position c ^ ((P >> 1) & 7).  LDS-DMA
-//     writes lane-linear, so the swizzle is applied on the SOURCE address; every ds_read_b128 lane group of every tap
-//     then covers 16 distinct bank quads (checked exhaustively: all taps, waves, sub-steps, both walk directions);
+//   * LDS image: pixel-major rows of 128 + 16 bytes -- conv_patch_kernel's conflict-free image (rotated tile rows).
+//     LDS-DMA writes lane-linear (16 bytes per lane, lane order), so a piece is 7 pixels = 63 lanes x 16 bytes with
+//     every ninth lane (the pad) and lane 63 switched off by EXEC: pieces abut at 1008-byte steps and pixel P sits at
+//     144 P exactly, so a tap is an IMMEDIATE offset of the fragment read -- no address arithmetic in the tap loop;
 //   * the tap loop is 72 MFMAs (v_mfma_f32_32x32x16_bf16) per wave with one A-fragment read each and NO barrier; one
 //     barrier per tile (patch t+1 landed / everyone is done with patch t-1);
 //   * epilogue per wave through a private LDS scratch (transpose to 16-byte NHWC pieces), no workgroup barrier; the
-//     BatchNorm statistics of tile t are folded across the four pixel groups after the next tile's barrier.
+//     BatchNorm statistics of a tile are folded across the four pixel groups two barriers later;
+//   * waves 4-7 run half a tile behind waves 0-3 (their SIMD partners): one wave of each SIMD is on the matrix pipe
+//     while the other writes its previous tile out.
 // Out-of-image patch pixels fail the buffer descriptor's range check and land as zeros (the conv's zero padding).
 #include "conv_igemm.h"
 
@@ -26,14 +29,17 @@ using namespace jspsr;
 
 constexpr int R_NTH = 512;                 // 8 waves
 constexpr int R_PW = 18, R_NPIX = R_PW * R_PW;
-constexpr int R_PIECES = (R_NPIX * 8 + 63) / 64;          // 41 one-KiB DMA pieces per patch
+constexpr int R_PITCH = 144;                              // LDS bytes per patch pixel: 128 + 16 (conflict-free ds_read_b128)
+constexpr int R_PPP = 7;                                  // pixels per DMA piece: 7 x 144 = 1008 B = 63 lanes x 16 B
+constexpr int R_PIECES = (R_NPIX + R_PPP - 1) / R_PPP;    // 47 pieces per patch
 constexpr int R_PIT = (R_PIECES + 7) / 8;                 // pieces per wave (wave w owns pieces w, w+8, ...)
-constexpr int R_PATCHB = R_PIECES * 1024;                 // 41984 B per patch buffer (multiple of 128)
+constexpr int R_PATCHB = R_PIECES * R_PPP * R_PITCH;      // 47376 B per patch buffer
+static_assert(R_PIT == 6, "issue_patch unpacks three registers of two piece codes");
 constexpr int R_SCRP = 80;                                // scratch row pitch: 64 B of channels + 16
 constexpr int R_SCRB = 64 * R_SCRP;                       // per wave
 constexpr int R_OFF_SCR = 2 * R_PATCHB;
-constexpr int R_OFF_RED = R_OFF_SCR + 8 * R_SCRB;         // [2][4][2][64] floats
-constexpr int R_LDS = R_OFF_RED + 2 * 4 * 2 * 64 * 4;
+constexpr int R_OFF_RED = R_OFF_SCR + 8 * R_SCRB;         // [3][4][2][64] floats
+constexpr int R_LDS = R_OFF_RED + 3 * 4 * 2 * 64 * 4;
 constexpr int R_ROT = 14;                                 // see conv_patch_kernel: row r of the tile is rotated by 14 r
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -60,18 +66,17 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       for (int s = 0; s < 4; ++s) breg[t][s] = *reinterpret_cast<const bf16x8*>(wrow + t * 128 + s * 32);
   }
 
-  // ---- patch DMA plan: lane `lane` of piece i fills 16-byte unit u = 64 i + lane = (pixel P, position q) ----------
+  // ---- patch DMA plan: lane l of piece i fills position l % 9 of pixel 7 i + l / 9 (position 8 = pad: lane off) ----
   const int pix_bytes = g.in_cstride * 2;
-  unsigned dsrc[R_PIT];        // byte offset of (pixel, chunk) from the patch origin
-  unsigned dyx[R_PIT];         // py | px << 8
+  const int lpix = lane / 9, lpos = lane - 9 * lpix;
+  const bool dma_lane = lane < 63 && lpos < 8;
+  unsigned dyx[R_PIT / 2];     // per piece 16 bits: py | px << 8 (two pieces per register; 0xffff beyond the patch)
 #pragma unroll
   for (int i = 0; i < R_PIT; ++i) {
-    const int u = (wave + 8 * i) * 64 + lane, P = u >> 3, q = u & 7;
-    const int c = q ^ ((P >> 1) & 7);
+    const int P = (wave + 8 * i) * R_PPP + lpix;
     const int py = P / R_PW, px = P - py * R_PW;
-    dsrc[i] = (unsigned)((py * g.IW + px) * pix_bytes + c * 16);
-    dyx[i] = (unsigned)(py | (px << 8));
-    if (P >= R_NPIX) dsrc[i] = 0xFFFFFFF0u;      // beyond the patch: zeros into the slack of the buffer
+    const unsigned code = P < R_NPIX ? (unsigned)(py | (px << 8)) : 0xffffu;
+    if (i & 1) dyx[i >> 1] |= code << 16; else dyx[i >> 1] = code;
   }
   const int back = SIGN < 0 ? 2 : 0;     // reversed walk: the patch starts two pixels earlier
 
@@ -90,25 +95,33 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     const long long opix0 = ((long long)bimg * g.IH + oy0) * g.IW + ox0;     // may lie outside the raster
     const char* base = reinterpret_cast<const char*>(in) + (opix0 * g.in_cstride + g.in_coff) * 2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xFFFFFF00u, 0x00020000);
+    // recompute the per-piece offsets here: hoisted as loop invariants they would cost 18 VGPRs (and spill)
+    unsigned dy0 = dyx[0], dy1 = dyx[1], dy2 = dyx[2];
+    int lp16 = lpos * 16;
+    asm volatile("" : "+v"(lp16), "+v"(dy0), "+v"(dy1), "+v"(dy2));
+    const unsigned dcode[3] = {dy0, dy1, dy2};
+    if (dma_lane) {
 #pragma unroll
-    for (int i = 0; i < R_PIT; ++i) {
-      if (wave + 8 * i < R_PIECES) {     // wave-uniform
-        const int py = dyx[i] & 0xff, px = dyx[i] >> 8;
-        const bool ok = (unsigned)(oy0 + py) < (unsigned)g.IH && (unsigned)(ox0 + px) < (unsigned)g.IW;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(smem + buf * R_PATCHB + (wave + 8 * i) * 1024), 16,
-                                                 ok ? dsrc[i] : 0xFFFFFFF0u, 0, 0, 0);
+      for (int i = 0; i < R_PIT; ++i) {
+        if (wave + 8 * i < R_PIECES) {     // wave-uniform
+          const unsigned code = (dcode[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+          const int py = code & 0xff, px = code >> 8;               // 255, 255 beyond the patch
+          const bool ok = code != 0xffffu && (unsigned)(oy0 + py) < (unsigned)g.IH && (unsigned)(ox0 + px) < (unsigned)g.IW;
+          const unsigned src = (unsigned)((py * g.IW + px) * pix_bytes + lp16);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(smem + buf * R_PATCHB + (wave + 8 * i) * (R_PPP * R_PITCH)), 16,
+                                                   ok ? src : 0xFFFFFFF0u, 0, 0, 0);
+        }
       }
     }
   };
 
   // ---- A-fragment plan ------------------------------------------------------------------------------------------
-  int Pl[2];
+  int a_base[2];      // LDS byte offset of this lane's fragment at tap 0 (reversed walk: at the LAST tap), sub-step 0
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const int R = wm * 64 + mi * 32 + lr, dy = R >> 4;
-    Pl[mi] = dy * R_PW + ((R + R_ROT * dy) & 15) + (SIGN < 0 ? 2 * R_PW + 2 : 0);
+    a_base[mi] = (dy * R_PW + ((R + R_ROT * dy) & 15)) * R_PITCH + lh * 16;
   }
-  const int lh16 = lh << 4;
 
   // ---- epilogue constants ---------------------------------------------------------------------------------------
   const int ncol = wn * 32 + lr;
@@ -133,32 +146,23 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     }
   };
 
-  int t = v, it = 0;
-  if (t < ntiles) issue_patch(t, 0);
-  for (; t < ntiles; t += G, ++it) {
-    const int buf = it & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and stores) have completed
-    __syncthreads();                                       // patch `buf` has landed; everyone has left tile t - G
-    if (stats && it > 0) flush_stats(t - G, buf ^ 1);
-    if (t + G < ntiles) issue_patch(t + G, buf ^ 1);
-
+  // Waves w and w + 4 share a SIMD.  Run in lockstep they would both be in their MFMA phase, then both in their
+  // epilogue (VALU / LDS / stores), and the matrix pipe would idle through every epilogue.  So waves 4-7 run HALF A TILE
+  // BEHIND: in the period of tile t (between two barriers) waves 0-3 multiply tile t and then write it out, while waves
+  // 4-7 first write out their part of tile t - G (accumulators kept across the barrier) and then multiply tile t -- each
+  // SIMD has one wave on the matrix pipe and one on the vector pipe at any time.  Statistics of a tile are therefore
+  // complete one period late: three parities of the fold buffer, folded two periods after the tile.
+  f32x16 acc[2];
+  auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
     // ---- 9 taps x 4 sub-steps x 2 row blocks, weights from registers ---------------------------------------------
-    f32x16 acc[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
-    int pl0 = Pl[0], pl1 = Pl[1];
-    asm volatile("" : "+v"(pl0), "+v"(pl1));      // keep the 18 tap addresses out of the loop-invariant registers
-    const char* const pbase = smem + buf * R_PATCHB;
-    auto a_addr = [&](int tap, int mi) __attribute__((always_inline)) {
-      const int tp = (tap / 3) * R_PW + tap % 3;
-      const int P = (mi ? pl1 : pl0) + SIGN * tp;
-      return (P << 7) + ((((P << 3) & 0x70)) ^ lh16);
-    };
-    constexpr int NK = 72, LA = 4;     // MFMA steps; fragment reads in flight ahead of their MFMA
+    const char* const pa0 = smem + buf * R_PATCHB + a_base[0];
+    const char* const pa1 = smem + buf * R_PATCHB + a_base[1];
+    constexpr int NK = 72, LA = 3;     // MFMA steps; fragment reads in flight ahead of their MFMA
     bf16x8 a[LA];
-    int ad[2];
 #pragma unroll
     for (int k = 0; k < NK + LA; ++k) {
       if (k >= LA) {                     // consumes ring slot k % LA before the read below refills it
@@ -167,8 +171,8 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       }
       if (k < NK) {
         const int tap = k >> 3, s = (k >> 1) & 3, mi = k & 1;
-        if (s == 0) ad[mi] = a_addr(tap, mi);
-        a[k % LA] = *reinterpret_cast<const bf16x8*>(pbase + (ad[mi] ^ (s * 32)));
+        const int tp = (tap / 3) * R_PW + tap % 3;                       // patch pixel offset of the tap
+        a[k % LA] = *reinterpret_cast<const bf16x8*>((mi ? pa1 : pa0) + (SIGN > 0 ? tp : 2 * R_PW + 2 - tp) * R_PITCH + s * 32);
       }
     }
     // pin the order: LA reads up front, then one read behind every MFMA (left alone, the scheduler sinks each read
@@ -180,9 +184,11 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       if (k + LA < NK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 
+  };
+  auto epilogue = [&](int te, int par) __attribute__((always_inline)) {
     // ---- epilogue: this wave's 64 pixels x 32 channels -------------------------------------------------------------
     int bimg, tyi, txi;
-    tile_coords(t, bimg, tyi, txi);
+    tile_coords(te, bimg, tyi, txi);
     const int ty0 = tyi * 16, tx0 = txi * 16;
     if (stats) {
       float s = 0.f, q = 0.f;
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       s += __shfl_xor(s, 32, 64);
       q += __shfl_xor(q, 32, 64);
       if (lh == 0) {
-        red[((buf * 4 + wm) * 2 + 0) * 64 + ncol] = s;
-        red[((buf * 4 + wm) * 2 + 1) * 64 + ncol] = q;
+        red[((par * 4 + wm) * 2 + 0) * 64 + ncol] = s;
+        red[((par * 4 + wm) * 2 + 1) * 64 + ncol] = q;
       }
     }
 #pragma unroll
@@ -255,10 +261,29 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
         *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + (opix * g.out_cstride + g.out_coff + wn * 32) * 2 + c16 * 16) = o;
       }
     }
+  };
+  const bool late = wave >= 4;
+  int t = v, it = 0;
+  if (t < ntiles) issue_patch(t, 0);
+  for (; t < ntiles; t += G, ++it) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and stores) have completed
+    __syncthreads();                                       // patch `buf` has landed; nobody reads patch `buf ^ 1` any more
+    if (stats && it > 1) flush_stats(t - 2 * G, (it - 2) % 3);
+    if (t + G < ntiles) issue_patch(t + G, buf ^ 1);
+    if (late) {
+      if (it > 0) epilogue(t - G, (it - 1) % 3);
+      mfma_tile(buf);
+    } else {
+      mfma_tile(buf);
+      epilogue(t, it % 3);
+    }
   }
+  if (late && it > 0) epilogue(t - G, (it - 1) % 3);
   if (stats && it > 0) {
     __syncthreads();
-    flush_stats(t - G, (it - 1) & 1);
+    if (it > 1) flush_stats(t - 2 * G, (it - 2) % 3);
+    flush_stats(t - G, (it - 1) % 3);
   }
 }
 
