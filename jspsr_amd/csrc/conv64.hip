@@ -40,9 +40,13 @@ constexpr int R_SCRB = 64 * R_SCRP;                       // per wave
 constexpr int R_OFF_SCR = 2 * R_PATCHB;
 constexpr int R_OFF_RED = R_OFF_SCR + 8 * R_SCRB;         // [3][4][2][64] floats
 constexpr int R_LDS = R_OFF_RED + 3 * 4 * 2 * 64 * 4;
+#ifndef K2R_LA
+#define K2R_LA 4      // A fragments requested ahead of their MFMA (lab builds: -DK2R_LA=n)
+#endif
 constexpr int R_ROT = 14;                                 // see conv_patch_kernel: row r of the tile is rotated by 14 r
 
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int SIGN>
 __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt,
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   const int lr = lane & 31, lh = lane >> 5;
   const int ttx = (g.MW + 15) >> 4, tty = (g.MH + 15) >> 4;
   const int G = gridDim.x;
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;      // LDS byte address of the dynamic segment
   const int v = xcd_contiguous(blockIdx.x, G);
 
   // ---- weights: 36 B fragments (9 taps x 4 sub-steps) of this wave's 32 output channels, once -------------------
@@ -94,7 +99,11 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     const int oy0 = tyi * 16 + g.iy_add - back, ox0 = txi * 16 + g.ix_add - back;
     const long long opix0 = ((long long)bimg * g.IH + oy0) * g.IW + ox0;     // may lie outside the raster
     const char* base = reinterpret_cast<const char*>(in) + (opix0 * g.in_cstride + g.in_coff) * 2;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xFFFFFF00u, 0x00020000);
+    // The DMA is issued from inline asm: hipcc orders every later LDS read of THIS wave (the epilogue's scratch) behind a
+    // builtin LDS-DMA with vmcnt(0), which also waits for the stores issued in between -- one exposed store latency per
+    // 16 rows written.  The waits that matter are placed by hand (after the MFMA phase, before the barrier).
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
+    const i32x4 desc = {(int)(unsigned)b64, (int)((unsigned)(b64 >> 32) & 0xffffu), (int)0xFFFFFF00u, 0x00020000};
     // recompute the per-piece offsets here: hoisted as loop invariants they would cost 18 VGPRs (and spill)
     unsigned dy0 = dyx[0], dy1 = dyx[1], dy2 = dyx[2];
     int lp16 = lpos * 16;
@@ -107,9 +116,11 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
           const unsigned code = (dcode[i >> 1] >> (16 * (i & 1))) & 0xffffu;
           const int py = code & 0xff, px = code >> 8;               // 255, 255 beyond the patch
           const bool ok = code != 0xffffu && (unsigned)(oy0 + py) < (unsigned)g.IH && (unsigned)(ox0 + px) < (unsigned)g.IW;
-          const unsigned src = (unsigned)((py * g.IW + px) * pix_bytes + lp16);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(smem + buf * R_PATCHB + (wave + 8 * i) * (R_PPP * R_PITCH)), 16,
-                                                   ok ? src : 0xFFFFFFF0u, 0, 0, 0);
+          const unsigned src = ok ? (unsigned)((py * g.IW + px) * pix_bytes + lp16) : 0xFFFFFFF0u;
+          const unsigned dst = lds0 + buf * R_PATCHB + (wave + 8 * i) * (R_PPP * R_PITCH);
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "s"(dst), "v"(src), "s"(desc) : "memory");
         }
       }
     }
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
     const char* const pa0 = smem + buf * R_PATCHB + a_base[0];
     const char* const pa1 = smem + buf * R_PATCHB + a_base[1];
-    constexpr int NK = 72, LA = 3;     // MFMA steps; fragment reads in flight ahead of their MFMA
+    constexpr int NK = 72, LA = K2R_LA;     // MFMA steps; fragment reads in flight ahead of their MFMA
     bf16x8 a[LA];
 #pragma unroll
     for (int k = 0; k < NK + LA; ++k) {
@@ -234,50 +245,76 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
         *reinterpret_cast<__bf16*>(scr + row * R_SCRP + lr * 2) = (__bf16)o;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private scratch: program order is enough
+    // 16-byte NHWC pieces out through buffer descriptors over the batch image's slice: 32-bit offsets, and a pixel
+    // outside the written raster gets an offset that fails the range check (the store / addend load is dropped)
     const int c16 = lane & 3, prow = lane >> 2;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(out) + ((long long)bimg * g.OH * g.OW * g.out_cstride + g.out_coff + wn * 32) * 2, 0, 0xFFFFFF00u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(g.addend)) + ((long long)bimg * g.OH * g.OW * g.add_cstride + wn * 32) * 2, 0,
+        g.addend ? 0xFFFFFF00u : 0u, 0x00020000);
+    // requests first (addend pieces, then the scratch rows), stores last: a load's result is never awaited with a
+    // store of this wave in flight
+    using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
+    unsigned ooff[4], aoff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int dy = wm * 4 + j;                              // tile row of scratch rows 16 j .. 16 j + 15
       const int y = ty0 + dy, x = tx0 + ((prow + R_ROT * dy) & 15);
-      uint4 o = *reinterpret_cast<const uint4*>(scr + (j * 16 + prow) * R_SCRP + c16 * 16);
-      if (y < g.MH && x < g.MW) {
-        const long long opix = ((long long)bimg * g.OH + y) * g.OW + x;
-        if (g.addend) {
-          const uint4 ad4 = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
-                                                           (opix * g.add_cstride + wn * 32) * 2 + c16 * 16);
-          const unsigned* pa = &o.x;
-          const unsigned* pb = &ad4.x;
-          unsigned pr[4];
+      const bool inside = y < g.MH && x < g.MW;
+      const unsigned pix = (unsigned)(y * g.OW + x);
+      ooff[j] = inside ? pix * (unsigned)(g.out_cstride * 2) + c16 * 16u : 0xFFFFFFF0u;
+      aoff[j] = inside ? pix * (unsigned)(g.add_cstride * 2) + c16 * 16u : 0xFFFFFFF0u;
+    }
+    if (g.addend) {
+      u32x4v av[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float lo = __uint_as_float(pa[i] << 16) + __uint_as_float(pb[i] << 16);
-            float hi = __uint_as_float(pa[i] & 0xffff0000u) + __uint_as_float(pb[i] & 0xffff0000u);
-            if (relu_last) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-            const __bf16 l = (__bf16)lo, h = (__bf16)hi;
-            pr[i] = (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
-          }
-          o = make_uint4(pr[0], pr[1], pr[2], pr[3]);
+      for (int j = 0; j < 4; ++j) av[j] = __builtin_amdgcn_raw_buffer_load_b128(adrsrc, aoff[j], 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 o = *reinterpret_cast<const uint4*>(scr + (j * 16 + prow) * R_SCRP + c16 * 16);
+        const unsigned pa[4] = {o.x, o.y, o.z, o.w};
+        u32x4v pr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float lo = __uint_as_float(pa[i] << 16) + __uint_as_float(av[j][i] << 16);
+          float hi = __uint_as_float(pa[i] & 0xffff0000u) + __uint_as_float(av[j][i] & 0xffff0000u);
+          if (relu_last) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+          const __bf16 l = (__bf16)lo, h = (__bf16)hi;
+          pr[i] = (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
         }
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out) + (opix * g.out_cstride + g.out_coff + wn * 32) * 2 + c16 * 16) = o;
+        __builtin_amdgcn_raw_buffer_store_b128(pr, orsrc, ooff[j], 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 o = *reinterpret_cast<const uint4*>(scr + (j * 16 + prow) * R_SCRP + c16 * 16);
+        const u32x4v ovv = {o.x, o.y, o.z, o.w};
+        __builtin_amdgcn_raw_buffer_store_b128(ovv, orsrc, ooff[j], 0, 0);
       }
     }
   };
   const bool late = wave >= 4;
   int t = v, it = 0;
   if (t < ntiles) issue_patch(t, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (; t < ntiles; t += G, ++it) {
     const int buf = it & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces (and stores) have completed
-    __syncthreads();                                       // patch `buf` has landed; nobody reads patch `buf ^ 1` any more
+    // every wave has waited for its own DMA pieces after its MFMA phase (below): patch `buf` is complete once all have
+    // arrived; nobody reads patch `buf ^ 1` any more.  The raw barrier does not wait for the stores of the epilogue.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (stats && it > 1) flush_stats(t - 2 * G, (it - 2) % 3);
-    if (t + G < ntiles) issue_patch(t + G, buf ^ 1);
     if (late) {
       if (it > 0) epilogue(t - G, (it - 1) % 3);
-      mfma_tile(buf);
-    } else {
-      mfma_tile(buf);
-      epilogue(t, it % 3);
+      if (t + G < ntiles) issue_patch(t + G, buf ^ 1);        // lands during this wave's MFMA phase
+    } else if (t + G < ntiles) {
+      issue_patch(t + G, buf ^ 1);
     }
+    mfma_tile(buf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA pieces issued above (long landed); no store is younger
+    if (!late) epilogue(t, it % 3);
   }
   if (late && it > 0) epilogue(t - G, (it - 1) % 3);
   if (stats && it > 0) {
@@ -301,6 +338,8 @@ bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, cons
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;
   if ((long long)(g.IW + 20) * 20 * g.in_cstride * 2 >= 0x7fffffffLL) return false;    // 32-bit offsets inside a patch
+  if ((long long)g.OH * g.OW * g.out_cstride * 2 >= 0xF0000000LL || (long long)g.OH * g.OW * g.add_cstride * 2 >= 0xF0000000LL)
+    return false;                                                                       // ... and inside one image of the result
   const long long tiles = (long long)g.B * ((g.MH + 15) / 16) * ((g.MW + 15) / 16);
   static const int min_tiles = [] { const char* e = getenv("JSPSR_CONV_RESIDENT_MIN"); return e ? atoi(e) : 1024; }();
   return tiles >= min_tiles && tiles < 0x7fffffffLL;
