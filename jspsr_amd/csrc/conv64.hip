@@ -47,6 +47,7 @@ constexpr int R_ROT = 14;                                 // see conv_patch_kern
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int SIGN>
 __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt,
@@ -85,17 +86,24 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   }
   const int back = SIGN < 0 ? 2 : 0;     // reversed walk: the patch starts two pixels earlier
 
-  auto tile_coords = [&](int t, int& bimg, int& tyi, int& txi) {
-    txi = t % ttx;
-    const int r = t / ttx;
-    tyi = r % tty;
-    bimg = r / tty;
+  // Tile coordinates advance by G tiles per period: carried incrementally (a few scalar adds) instead of two divisions
+  // per use -- the scalar unit shares this wave's issue slot with the epilogue it would otherwise lengthen.
+  struct Tile { int bimg, tyi, txi; };
+  const int dGx = G % ttx, dGy = (G / ttx) % tty, dGb = G / (ttx * tty);
+  auto advance = [&](Tile c) {
+    c.txi += dGx;
+    int carry = c.txi >= ttx;
+    c.txi -= carry ? ttx : 0;
+    c.tyi += dGy + carry;
+    carry = c.tyi >= tty;
+    c.tyi -= carry ? tty : 0;
+    c.bimg += dGb + carry;
+    return c;
   };
   // A lane whose pixel lies outside the image (or beyond the patch) gets an offset that fails the descriptor's range
   // check: `buffer_load ... lds` then writes ZEROS for it (tools/lab/lds_dma_oob.hip) -- the conv's zero padding.
-  auto issue_patch = [&](int t, int buf) __attribute__((always_inline)) {
-    int bimg, tyi, txi;
-    tile_coords(t, bimg, tyi, txi);
+  auto issue_patch = [&](Tile tc, int buf) __attribute__((always_inline)) {
+    const int bimg = tc.bimg, tyi = tc.tyi, txi = tc.txi;
     const int oy0 = tyi * 16 + g.iy_add - back, ox0 = txi * 16 + g.ix_add - back;
     const long long opix0 = ((long long)bimg * g.IH + oy0) * g.IW + ox0;     // may lie outside the raster
     const char* base = reinterpret_cast<const char*>(in) + (opix0 * g.in_cstride + g.in_coff) * 2;
@@ -109,18 +117,23 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     int lp16 = lpos * 16;
     asm volatile("" : "+v"(lp16), "+v"(dy0), "+v"(dy1), "+v"(dy2));
     const unsigned dcode[3] = {dy0, dy1, dy2};
+    // M0 (the DMA's LDS base) is written by each statement that uses it; nothing else in this kernel uses M0
+    const bool interior = oy0 >= 0 && ox0 >= 0 && oy0 + R_PW <= g.IH && ox0 + R_PW <= g.IW;    // wave-uniform
     if (dma_lane) {
 #pragma unroll
       for (int i = 0; i < R_PIT; ++i) {
         if (wave + 8 * i < R_PIECES) {     // wave-uniform
           const unsigned code = (dcode[i >> 1] >> (16 * (i & 1))) & 0xffffu;
           const int py = code & 0xff, px = code >> 8;               // 255, 255 beyond the patch
-          const bool ok = code != 0xffffu && (unsigned)(oy0 + py) < (unsigned)g.IH && (unsigned)(ox0 + px) < (unsigned)g.IW;
-          const unsigned src = ok ? (unsigned)((py * g.IW + px) * pix_bytes + lp16) : 0xFFFFFFF0u;
+          unsigned src = (unsigned)((py * g.IW + px) * pix_bytes + lp16);
+          if (interior) {
+            if (i == R_PIT - 1 || wave + 8 * i == R_PIECES - 1) src = code != 0xffffu ? src : 0xFFFFFFF0u;   // only the last piece runs past the patch
+          } else {
+            const bool ok = code != 0xffffu && (unsigned)(oy0 + py) < (unsigned)g.IH && (unsigned)(ox0 + px) < (unsigned)g.IW;
+            src = ok ? src : 0xFFFFFFF0u;
+          }
           const unsigned dst = lds0 + buf * R_PATCHB + (wave + 8 * i) * (R_PPP * R_PITCH);
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "s"(dst), "v"(src), "s"(desc) : "memory");
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src), "s"(desc) : "memory");
         }
       }
     }
@@ -137,17 +150,16 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   // ---- epilogue constants ---------------------------------------------------------------------------------------
   const int ncol = wn * 32 + lr;
   const float bv = bias ? bias[ncol] : 0.f, sv = g.scale ? g.scale[ncol] : 1.f;
-  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend;
+  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend, affine = bias || g.scale;
   char* const scr = smem + R_OFF_SCR + wave * R_SCRB;
   float* const red = reinterpret_cast<float*>(smem + R_OFF_RED);
   const int tty8 = (g.MH + 7) >> 3;
 
-  auto flush_stats = [&](int t, int par) __attribute__((always_inline)) {
+  auto flush_stats = [&](Tile tc, int par) __attribute__((always_inline)) {
     // rows of the statistics buffer are numbered by 8x16-pixel tiles (jspsr_conv2d_stats_rows): pixel groups 0,1 are
     // the upper half of this 16x16 tile, 2,3 the lower
     if (tid < 256) {
-      int bimg, tyi, txi;
-      tile_coords(t, bimg, tyi, txi);
+      const int bimg = tc.bimg, tyi = tc.tyi, txi = tc.txi;
       const int half = tid >> 7, which = (tid >> 6) & 1, col = tid & 63;
       const int row = 2 * tyi + half;
       if (row < tty8) {
@@ -196,22 +208,24 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     }
 
   };
-  auto epilogue = [&](int te, int par) __attribute__((always_inline)) {
+  auto epilogue = [&](Tile tc, int par) __attribute__((always_inline)) {
     // ---- epilogue: this wave's 64 pixels x 32 channels -------------------------------------------------------------
-    int bimg, tyi, txi;
-    tile_coords(te, bimg, tyi, txi);
+    const int bimg = tc.bimg, tyi = tc.tyi, txi = tc.txi;
     const int ty0 = tyi * 16, tx0 = txi * 16;
     if (stats) {
       float s = 0.f, q = 0.f;
       if (ty0 + 16 <= g.MH && tx0 + 16 <= g.MW) {          // interior tile (wave-uniform): every row counts
+        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};              // two rows per v_pk_add_f32 / v_pk_fma_f32
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float a0 = acc[mi][e];
-            s += a0;
-            q += a0 * a0;
+          for (int e = 0; e < 16; e += 2) {
+            const f32x2 a2 = {acc[mi][e], acc[mi][e + 1]};
+            s2 += a2;
+            q2 = __builtin_elementwise_fma(a2, a2, q2);
           }
+        s = s2[0] + s2[1];
+        q = q2[0] + q2[1];
       } else {
         int lh4 = 4 * lh;
         asm volatile("" : "+v"(lh4));                       // keep the 32 row coordinates out of the loop-invariant registers
@@ -240,7 +254,8 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float o = acc[mi][e] * sv + bv;
+        float o = acc[mi][e];
+        if (affine) o = o * sv + bv;
         if (relu_first) o = fmaxf(o, 0.f);
         *reinterpret_cast<__bf16*>(scr + row * R_SCRP + lr * 2) = (__bf16)o;
       }
@@ -257,11 +272,12 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     // store of this wave in flight
     using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
     unsigned ooff[4], aoff[4];
+    const bool whole = ty0 + 16 <= g.MH && tx0 + 16 <= g.MW;      // wave-uniform: no pixel of the tile is outside
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int dy = wm * 4 + j;                              // tile row of scratch rows 16 j .. 16 j + 15
       const int y = ty0 + dy, x = tx0 + ((prow + R_ROT * dy) & 15);
-      const bool inside = y < g.MH && x < g.MW;
+      const bool inside = whole || (y < g.MH && x < g.MW);
       const unsigned pix = (unsigned)(y * g.OW + x);
       ooff[j] = inside ? pix * (unsigned)(g.out_cstride * 2) + c16 * 16u : 0xFFFFFFF0u;
       aoff[j] = inside ? pix * (unsigned)(g.add_cstride * 2) + c16 * 16u : 0xFFFFFFF0u;
@@ -296,31 +312,52 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   };
   const bool late = wave >= 4;
   int t = v, it = 0;
-  if (t < ntiles) issue_patch(t, 0);
+  Tile tcur{(v / ttx) / tty, (v / ttx) % tty, v % ttx}, tprev = tcur, tprev2 = tcur, tnext = advance(tcur);
+  if (t < ntiles) issue_patch(tcur, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef K2R_STAMPS      // lab build: cycles per phase, printed by waves 0 and 4 of workgroup 0 (tools/lab/build_k2r_variants.sh)
+  unsigned long long st_bar = 0, st_pre = 0, st_mfma = 0, st_vm = 0, st_post = 0, s0, s1;
+#define K2R_STAMP(acc_) do { s1 = __builtin_readcyclecounter(); acc_ += s1 - s0; s0 = s1; } while (0)
+#else
+#define K2R_STAMP(acc_) do { } while (0)
+#endif
   for (; t < ntiles; t += G, ++it) {
     const int buf = it & 1;
+#ifdef K2R_STAMPS
+    s0 = __builtin_readcyclecounter();
+#endif
     // every wave has waited for its own DMA pieces after its MFMA phase (below): patch `buf` is complete once all have
     // arrived; nobody reads patch `buf ^ 1` any more.  The raw barrier does not wait for the stores of the epilogue.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (stats && it > 1) flush_stats(t - 2 * G, (it - 2) % 3);
+    K2R_STAMP(st_bar);
+    if (stats && it > 1) flush_stats(tprev2, (it - 2) % 3);
     if (late) {
-      if (it > 0) epilogue(t - G, (it - 1) % 3);
-      if (t + G < ntiles) issue_patch(t + G, buf ^ 1);        // lands during this wave's MFMA phase
+      if (it > 0) epilogue(tprev, (it - 1) % 3);
+      if (t + G < ntiles) issue_patch(tnext, buf ^ 1);        // lands during this wave's MFMA phase
     } else if (t + G < ntiles) {
-      issue_patch(t + G, buf ^ 1);
+      issue_patch(tnext, buf ^ 1);
     }
+    K2R_STAMP(st_pre);
     mfma_tile(buf);
+    K2R_STAMP(st_mfma);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA pieces issued above (long landed); no store is younger
-    if (!late) epilogue(t, it % 3);
+    K2R_STAMP(st_vm);
+    if (!late) epilogue(tcur, it % 3);
+    tprev2 = tprev; tprev = tcur; tcur = tnext; tnext = advance(tnext);
+    K2R_STAMP(st_post);
   }
-  if (late && it > 0) epilogue(t - G, (it - 1) % 3);
+#ifdef K2R_STAMPS
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
+    printf("K2R wave %d tiles %d: barrier %llu  pre-mfma %llu  mfma %llu  vmcnt %llu  post-mfma %llu (cycles per tile)\n", wave, it,
+           st_bar / it, st_pre / it, st_mfma / it, st_vm / it, st_post / it);
+#endif
+  if (late && it > 0) epilogue(tprev, (it - 1) % 3);
   if (stats && it > 0) {
     __syncthreads();
-    if (it > 1) flush_stats(t - 2 * G, (it - 2) % 3);
-    flush_stats(t - G, (it - 1) % 3);
+    if (it > 1) flush_stats(tprev2, (it - 2) % 3);
+    flush_stats(tprev, (it - 1) % 3);
   }
 }
 

@@ -1,13 +1,16 @@
 #!/bin/bash
 # Lab: libjspsr_hip.so variants of K2r (conv64.hip) with different fragment look-ahead depths -> jspsr_amd/lib/lab_k2r_la<N>.so
-# (picked up through JSPSR_LAB_LIB by tools/bench_conv.py).  Usage: tools/lab/build_k2r_variants.sh 3 4 6 8 10
+# (picked up through JSPSR_LAB_LIB by tools/bench_conv.py).  Usage: tools/lab/build_k2r_variants.sh 3 4 6 8 10 [stamps]
 set -e
 cd "$(dirname "$0")/../../jspsr_amd/csrc"
 make -s -j6
 for la in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DK2R_LA=$la -c conv64.hip -o _obj/conv64_la$la.o
+  extra=""
+  if [ "$la" = "stamps" ]; then extra="-DK2R_STAMPS"; la=4; fi      # per-phase cycle counters printed by two waves
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DK2R_LA=$la $extra -c conv64.hip -o _obj/conv64_la$la.o
   objs=$(ls _obj/*.o | grep -v "conv64")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/lab_k2r_la$la.so $objs _obj/conv64_la$la.o
+  name=lab_k2r_la$la; [ -n "$extra" ] && name=lab_k2r_stamps
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/$name.so $objs _obj/conv64_la$la.o
   rm _obj/conv64_la$la.o
 done
 ls -la ../lib
