@@ -4,24 +4,33 @@
 // have K = 9 * 64 = 576 and N = 64: the whole weight matrix is 73.7 KB.  conv_patch_kernel streams it from L2 once per
 // 256-pixel tile behind a barrier per tap and pays a cold patch load per tile (PMC, round 1: 28-34 % of the wave cycles
 // parked on the stage barrier / weight vmcnt).  Here a PERSISTENT workgroup per CU (8 waves = 4 pixel groups x 2
-// channel groups, each wave 64 pixels x 32 channels) loads its 32 weight rows ONCE into 144 VGPRs (36 MFMA B
+// channel groups, each wave 64 pixels x 32 channels) loads its 32 weight rows ONCE into 144 VGPRs (36 MFMA
 // fragments) and walks tiles of 16x16 pixels:
-//   * the 18x18-pixel input patch of tile t+1 arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 47 pieces of 7 pixels) into the
-//     second patch buffer while tile t is multiplied -- no staging registers, no ds_write pass, no cold prologue;
+//   * the 18x18-pixel input patch of tile t+1 arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 47 pieces of 7 pixels)
+//     into the second patch buffer while tile t is multiplied -- no staging registers, no ds_write pass, no cold
+//     prologue.  A piece costs its wave 100-200 issue cycles (MI355X_MICROARCH.md; measured here ~270 with 25
+//     instructions of address arithmetic and EXEC masking around it, wherever it is placed), so a piece is three
+//     instructions: the per-lane source offsets of interior tiles are tile-invariant registers;
 //   * LDS image: pixel-major rows of 128 + 16 bytes -- conv_patch_kernel's conflict-free image (rotated tile rows).
-//     LDS-DMA writes lane-linear (16 bytes per lane, lane order), so a piece is 7 pixels = 63 lanes x 16 bytes with
-//     every ninth lane (the pad) and lane 63 switched off by EXEC: pieces abut at 1008-byte steps and pixel P sits at
-//     144 P exactly, so a tap is an IMMEDIATE offset of the fragment read -- no address arithmetic in the tap loop;
-//   * the tap loop is 72 MFMAs (v_mfma_f32_32x32x16_bf16) per wave with one A-fragment read each and NO barrier; one
-//     barrier per tile (patch t+1 landed / everyone is done with patch t-1);
-//   * epilogue per wave through a private LDS scratch (transpose to 16-byte NHWC pieces), no workgroup barrier; the
-//     BatchNorm statistics of a tile are folded across the four pixel groups two barriers later;
+//     LDS-DMA writes lane-linear (16 bytes per lane, lane order), so a piece is 7 pixels = 63 lanes x 16 bytes: every
+//     ninth lane lands zeros in the pad, lane 63 writes the first 16 bytes of the NEXT piece's first pixel (the same
+//     bytes that piece's lane 0 writes).  Pieces abut at 1008-byte steps and pixel P sits at 144 P exactly, so a tap is an
+//     IMMEDIATE offset of the fragment read -- no address arithmetic in the tap loop;
+//   * the tap loop is 72 MFMAs (v_mfma_f32_32x32x16_bf16) per wave with one patch-fragment read each and NO barrier;
+//     one barrier per tile (patch t+1 landed / everyone is done with patch t-1);
 //   * waves 4-7 run half a tile behind waves 0-3 (their SIMD partners): one wave of each SIMD is on the matrix pipe
-//     while the other writes its previous tile out.
+//     while the other writes its previous tile out;
+//   * two epilogues.  Without statistics or a per-channel scale / bias (data gradient, plain convs) the MFMA operands are SWAPPED, so a lane holds
+//     sixteen CHANNELS of one pixel: v_cvt_pk_bf16_f32 pairs them, v_permlane32_swap joins the two half-waves' groups
+//     of four into 16-byte NHWC pieces, and the tile goes out from registers -- no LDS, ~40 vector instructions.  With
+//     BatchNorm statistics (training forward) a lane holds one channel of sixteen pixels, the per-channel sums are
+//     in-lane adds, and the tile is transposed through a wave-private LDS scratch; the statistics of a tile are folded
+//     across the four pixel groups two barriers later.
 // Out-of-image patch pixels fail the buffer descriptor's range check and land as zeros (the conv's zero padding).
 #include "conv_igemm.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -31,38 +40,70 @@ constexpr int R_NTH = 512;                 // 8 waves
 constexpr int R_PW = 18, R_NPIX = R_PW * R_PW;
 constexpr int R_PITCH = 144;                              // LDS bytes per patch pixel: 128 + 16 (conflict-free ds_read_b128)
 constexpr int R_PPP = 7;                                  // pixels per DMA piece: 7 x 144 = 1008 B = 63 lanes x 16 B
+constexpr int R_PIECEB = R_PPP * R_PITCH;
 constexpr int R_PIECES = (R_NPIX + R_PPP - 1) / R_PPP;    // 47 pieces per patch
-constexpr int R_PIT = (R_PIECES + 7) / 8;                 // pieces per wave (wave w owns pieces w, w+8, ...)
-constexpr int R_PATCHB = R_PIECES * R_PPP * R_PITCH;      // 47376 B per patch buffer
-static_assert(R_PIT == 6, "issue_patch unpacks three registers of two piece codes");
+#ifndef K2R_EARLY
+#define K2R_EARLY 8     // pieces per patch requested by each of waves 0-3; waves 4-7 share the rest (lab: -DK2R_EARLY=n)
+#endif
+constexpr int R_PE = K2R_EARLY, R_PL = (R_PIECES - 4 * R_PE + 3) / 4;      // waves 4-7 have the longer pre-MFMA part (an epilogue)
+constexpr int R_PIT = R_PE > R_PL ? R_PE : R_PL;
+constexpr int R_PATCHB = R_PIECES * R_PIECEB + 16;        // 47392 B per patch buffer (+16: lane 63 of the last piece)
 constexpr int R_SCRP = 80;                                // scratch row pitch: 64 B of channels + 16
 constexpr int R_SCRB = 64 * R_SCRP;                       // per wave
 constexpr int R_OFF_SCR = 2 * R_PATCHB;
 constexpr int R_OFF_RED = R_OFF_SCR + 8 * R_SCRB;         // [3][4][2][64] floats
-constexpr int R_LDS = R_OFF_RED + 3 * 4 * 2 * 64 * 4;
+constexpr int R_LDS_STATS = R_OFF_RED + 3 * 4 * 2 * 64 * 4;
+constexpr int R_LDS_PLAIN = 2 * R_PATCHB;
 #ifndef K2R_LA
-#define K2R_LA 4      // A fragments requested ahead of their MFMA (lab builds: -DK2R_LA=n)
+#define K2R_LA 4      // patch fragments requested ahead of their MFMA (lab builds: -DK2R_LA=n)
 #endif
 constexpr int R_ROT = 14;                                 // see conv_patch_kernel: row r of the tile is rotated by 14 r
+constexpr int NK = 72, LA = K2R_LA;                       // MFMA steps per tile; look-ahead
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int SIGN>
+struct Tile { int bimg, tyi, txi; };
+struct PatchSrc { i32x4 desc; int oy0, ox0; bool interior; };
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // one v_cvt_pk_bf16_f32
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// max(x, 0) on the bit pattern: one v_max_i32 (a negative float is a negative integer; -0 and negative NaNs become +0)
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// 8 bf16 + 8 bf16 (fp32 add, one rounding), optional ReLU
+__device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b, bool relu) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
+    float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
+    if (relu) { lo = relu_bits(lo); hi = relu_bits(hi); }
+    r[i] = pack_bf16(lo, hi);
+  }
+  return r;
+}
+
+template <int SIGN, bool STATS>
 __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt,
                                                                   const float* __restrict__ bias, __bf16* __restrict__ out,
                                                                   float* __restrict__ stats, ConvGeom g, int ntiles) {
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = (wave >> 1) & 3, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
   const int ttx = (g.MW + 15) >> 4, tty = (g.MH + 15) >> 4;
   const int G = gridDim.x;
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;      // LDS byte address of the dynamic segment
   const int v = xcd_contiguous(blockIdx.x, G);
+  const bool late = wave >= 4;
 
-  // ---- weights: 36 B fragments (9 taps x 4 sub-steps) of this wave's 32 output channels, once -------------------
+  // ---- weights: 36 fragments (9 taps x 4 sub-steps) of this wave's 32 output channels, once ------------------------
   bf16x8 breg[9][4];
   {
     const char* wrow = reinterpret_cast<const char*>(wgt) + (size_t)(wn * 32 + lr) * (9 * 64 * 2) + lh * 16;
@@ -72,23 +113,8 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       for (int s = 0; s < 4; ++s) breg[t][s] = *reinterpret_cast<const bf16x8*>(wrow + t * 128 + s * 32);
   }
 
-  // ---- patch DMA plan: lane l of piece i fills position l % 9 of pixel 7 i + l / 9 (position 8 = pad: lane off) ----
-  const int pix_bytes = g.in_cstride * 2;
-  const int lpix = lane / 9, lpos = lane - 9 * lpix;
-  const bool dma_lane = lane < 63 && lpos < 8;
-  unsigned dyx[R_PIT / 2];     // per piece 16 bits: py | px << 8 (two pieces per register; 0xffff beyond the patch)
-#pragma unroll
-  for (int i = 0; i < R_PIT; ++i) {
-    const int P = (wave + 8 * i) * R_PPP + lpix;
-    const int py = P / R_PW, px = P - py * R_PW;
-    const unsigned code = P < R_NPIX ? (unsigned)(py | (px << 8)) : 0xffffu;
-    if (i & 1) dyx[i >> 1] |= code << 16; else dyx[i >> 1] = code;
-  }
-  const int back = SIGN < 0 ? 2 : 0;     // reversed walk: the patch starts two pixels earlier
-
   // Tile coordinates advance by G tiles per period: carried incrementally (a few scalar adds) instead of two divisions
-  // per use -- the scalar unit shares this wave's issue slot with the epilogue it would otherwise lengthen.
-  struct Tile { int bimg, tyi, txi; };
+  // per use -- the scalar unit shares this wave's issue slot with everything else it does.
   const int dGx = G % ttx, dGy = (G / ttx) % tty, dGb = G / (ttx * tty);
   auto advance = [&](Tile c) {
     c.txi += dGx;
@@ -100,46 +126,58 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     c.bimg += dGb + carry;
     return c;
   };
-  // A lane whose pixel lies outside the image (or beyond the patch) gets an offset that fails the descriptor's range
-  // check: `buffer_load ... lds` then writes ZEROS for it (tools/lab/lds_dma_oob.hip) -- the conv's zero padding.
-  auto issue_patch = [&](Tile tc, int buf) __attribute__((always_inline)) {
-    const int bimg = tc.bimg, tyi = tc.tyi, txi = tc.txi;
-    const int oy0 = tyi * 16 + g.iy_add - back, ox0 = txi * 16 + g.ix_add - back;
-    const long long opix0 = ((long long)bimg * g.IH + oy0) * g.IW + ox0;     // may lie outside the raster
-    const char* base = reinterpret_cast<const char*>(in) + (opix0 * g.in_cstride + g.in_coff) * 2;
-    // The DMA is issued from inline asm: hipcc orders every later LDS read of THIS wave (the epilogue's scratch) behind a
-    // builtin LDS-DMA with vmcnt(0), which also waits for the stores issued in between -- one exposed store latency per
-    // 16 rows written.  The waits that matter are placed by hand (after the MFMA phase, before the barrier).
-    const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
-    const i32x4 desc = {(int)(unsigned)b64, (int)((unsigned)(b64 >> 32) & 0xffffu), (int)0xFFFFFF00u, 0x00020000};
-    // recompute the per-piece offsets here: hoisted as loop invariants they would cost 18 VGPRs (and spill)
-    unsigned dy0 = dyx[0], dy1 = dyx[1], dy2 = dyx[2];
-    int lp16 = lpos * 16;
-    asm volatile("" : "+v"(lp16), "+v"(dy0), "+v"(dy1), "+v"(dy2));
-    const unsigned dcode[3] = {dy0, dy1, dy2};
-    // M0 (the DMA's LDS base) is written by each statement that uses it; nothing else in this kernel uses M0
-    const bool interior = oy0 >= 0 && ox0 >= 0 && oy0 + R_PW <= g.IH && ox0 + R_PW <= g.IW;    // wave-uniform
-    if (dma_lane) {
+
+  // ---- patch DMA: lane l of piece i fills position l % 9 of pixel 7 i + l / 9 (position 8 = the 16-byte pad) --------
+  const int pix_bytes = g.in_cstride * 2;
+  const int lpix = lane / 9, lp16 = (lane - 9 * lpix) * 16;      // lane 63: pixel 7 (the next piece's first), position 0
+  const int back = SIGN < 0 ? 2 : 0;     // reversed walk: the patch starts two pixels earlier
+  // source offset of this lane in its i-th piece, from the patch origin: tile-invariant (pad lanes and pixels beyond the
+  // patch: an offset that fails the descriptor's range check -> zeros)
+  // wave w < 4 owns pieces w + 4 i (i < R_PE), wave w >= 4 pieces 4 R_PE + (w - 4) + 4 i (i < R_PL)
+  const int piece0 = late ? 4 * R_PE + (wave - 4) : wave, npiece = late ? R_PL : R_PE;
+  unsigned dsrc[R_PIT];
 #pragma unroll
-      for (int i = 0; i < R_PIT; ++i) {
-        if (wave + 8 * i < R_PIECES) {     // wave-uniform
-          const unsigned code = (dcode[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-          const int py = code & 0xff, px = code >> 8;               // 255, 255 beyond the patch
-          unsigned src = (unsigned)((py * g.IW + px) * pix_bytes + lp16);
-          if (interior) {
-            if (i == R_PIT - 1 || wave + 8 * i == R_PIECES - 1) src = code != 0xffffu ? src : 0xFFFFFFF0u;   // only the last piece runs past the patch
-          } else {
-            const bool ok = code != 0xffffu && (unsigned)(oy0 + py) < (unsigned)g.IH && (unsigned)(ox0 + px) < (unsigned)g.IW;
-            src = ok ? src : 0xFFFFFFF0u;
-          }
-          const unsigned dst = lds0 + buf * R_PATCHB + (wave + 8 * i) * (R_PPP * R_PITCH);
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src), "s"(desc) : "memory");
+  for (int i = 0; i < R_PIT; ++i) {
+    const int P = (piece0 + 4 * i) * R_PPP + lpix;
+    const int py = P / R_PW, px = P - py * R_PW;
+    dsrc[i] = (lp16 < 128 && P < R_NPIX) ? (unsigned)((py * g.IW + px) * pix_bytes + lp16) : 0xFFFFFFF0u;
+  }
+  auto patch_src = [&](Tile tc) {
+    PatchSrc p;
+    p.oy0 = tc.tyi * 16 + g.iy_add - back;
+    p.ox0 = tc.txi * 16 + g.ix_add - back;
+    const long long opix0 = ((long long)tc.bimg * g.IH + p.oy0) * g.IW + p.ox0;     // may lie outside the raster
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(in) + (opix0 * g.in_cstride + g.in_coff) * 2;
+    p.desc = i32x4{(int)(unsigned)b64, (int)((unsigned)(b64 >> 32) & 0xffffu), (int)0xFFFFFF00u, 0x00020000};
+    p.interior = p.oy0 >= 0 && p.ox0 >= 0 && p.oy0 + R_PW <= g.IH && p.ox0 + R_PW <= g.IW;    // wave-uniform
+    return p;
+  };
+  // This wave's pieces of one patch.  A lane whose pixel lies outside the image gets an offset that fails the descriptor's
+  // range check: `buffer_load ... lds` then writes ZEROS for it (tools/lab/lds_dma_oob.hip) -- the conv's zero padding;
+  // only tiles on the image border pay for that test.  Issued from inline asm (no memory clobber: the bytes land in the
+  // OTHER patch buffer, read after the next barrier): hipcc would order every later LDS read of this wave behind a
+  // builtin LDS-DMA with vmcnt(0), and behind a clobbering statement with lgkmcnt(0); the waits that matter are placed
+  // by hand.  M0 is written in the statement that uses it (nothing else in this kernel uses M0).
+  auto issue_patch = [&](const PatchSrc& p, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < R_PIT; ++i) {
+      if (i < npiece && piece0 + 4 * i < R_PIECES) {     // wave-uniform
+        unsigned src = dsrc[i];
+        if (!p.interior) {
+          int lpix_ = lpix;
+          asm volatile("" : "+v"(lpix_));                       // border tiles only: recomputed, not kept in registers
+          const int P = (piece0 + 4 * i) * R_PPP + lpix_;
+          const int py = (int)(__umul24(P, 3641) >> 16), px = P - (int)__umul24(py, R_PW);        // P / 18 for P < 400
+          const bool in_img = (unsigned)(p.oy0 + py) < (unsigned)g.IH && (unsigned)(p.ox0 + px) < (unsigned)g.IW;
+          src = in_img ? src : 0xFFFFFFF0u;
         }
+        const unsigned dst = lds0 + buf * R_PATCHB + (piece0 + 4 * i) * R_PIECEB;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src), "s"(p.desc));
       }
     }
   };
 
-  // ---- A-fragment plan ------------------------------------------------------------------------------------------
+  // ---- patch-fragment plan ---------------------------------------------------------------------------------------
   int a_base[2];      // LDS byte offset of this lane's fragment at tap 0 (reversed walk: at the LAST tap), sub-step 0
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
@@ -147,50 +185,22 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     a_base[mi] = (dy * R_PW + ((R + R_ROT * dy) & 15)) * R_PITCH + lh * 16;
   }
 
-  // ---- epilogue constants ---------------------------------------------------------------------------------------
-  const int ncol = wn * 32 + lr;
-  const float bv = bias ? bias[ncol] : 0.f, sv = g.scale ? g.scale[ncol] : 1.f;
-  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend, affine = bias || g.scale;
-  char* const scr = smem + R_OFF_SCR + wave * R_SCRB;
-  float* const red = reinterpret_cast<float*>(smem + R_OFF_RED);
-  const int tty8 = (g.MH + 7) >> 3;
-
-  auto flush_stats = [&](Tile tc, int par) __attribute__((always_inline)) {
-    // rows of the statistics buffer are numbered by 8x16-pixel tiles (jspsr_conv2d_stats_rows): pixel groups 0,1 are
-    // the upper half of this 16x16 tile, 2,3 the lower
-    if (tid < 256) {
-      const int bimg = tc.bimg, tyi = tc.tyi, txi = tc.txi;
-      const int half = tid >> 7, which = (tid >> 6) & 1, col = tid & 63;
-      const int row = 2 * tyi + half;
-      if (row < tty8) {
-        const float* r0 = red + ((par * 4 + 2 * half) * 2 + which) * 64 + col;
-        stats[((size_t)((bimg * tty8 + row) * ttx + txi) * 2 + which) * 64 + col] = r0[0] + r0[2 * 64];
-      }
-    }
-  };
-
-  // Waves w and w + 4 share a SIMD.  Run in lockstep they would both be in their MFMA phase, then both in their
-  // epilogue (VALU / LDS / stores), and the matrix pipe would idle through every epilogue.  So waves 4-7 run HALF A TILE
-  // BEHIND: in the period of tile t (between two barriers) waves 0-3 multiply tile t and then write it out, while waves
-  // 4-7 first write out their part of tile t - G (accumulators kept across the barrier) and then multiply tile t -- each
-  // SIMD has one wave on the matrix pipe and one on the vector pipe at any time.  Statistics of a tile are therefore
-  // complete one period late: three parities of the fold buffer, folded two periods after the tile.
+  // ---- the tap loop: 9 taps x 4 sub-steps x 2 pixel blocks, weights from registers ------------------------------------
   f32x16 acc[2];
   auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
-    // ---- 9 taps x 4 sub-steps x 2 row blocks, weights from registers ---------------------------------------------
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
     const char* const pa0 = smem + buf * R_PATCHB + a_base[0];
     const char* const pa1 = smem + buf * R_PATCHB + a_base[1];
-    constexpr int NK = 72, LA = K2R_LA;     // MFMA steps; fragment reads in flight ahead of their MFMA
     bf16x8 a[LA];
 #pragma unroll
     for (int k = 0; k < NK + LA; ++k) {
       if (k >= LA) {                     // consumes ring slot k % LA before the read below refills it
         const int kk = k - LA, tap = kk >> 3, s = (kk >> 1) & 3, mi = kk & 1;
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % LA], breg[tap][s], acc[mi], 0, 0, 0);
+        if (STATS) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk % LA], breg[tap][s], acc[mi], 0, 0, 0);   // rows = pixels
+        else       acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[tap][s], a[kk % LA], acc[mi], 0, 0, 0);   // rows = channels
       }
       if (k < NK) {
         const int tap = k >> 3, s = (k >> 1) & 3, mi = k & 1;
@@ -198,23 +208,56 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
         a[k % LA] = *reinterpret_cast<const bf16x8*>((mi ? pa1 : pa0) + (SIGN > 0 ? tp : 2 * R_PW + 2 - tp) * R_PITCH + s * 32);
       }
     }
-    // pin the order: LA reads up front, then one read behind every MFMA (left alone, the scheduler sinks each read
-    // to just before its use and the MFMA waits out the LDS latency)
+    // pin the order: LA reads up front, then one read behind every MFMA (left alone, the scheduler sinks each read to
+    // just before its use and the MFMA waits out the LDS latency)
     __builtin_amdgcn_sched_group_barrier(0x100, LA, 0);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if (k + LA < NK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-
   };
-  auto epilogue = [&](Tile tc, int par) __attribute__((always_inline)) {
-    // ---- epilogue: this wave's 64 pixels x 32 channels -------------------------------------------------------------
-    const int bimg = tc.bimg, tyi = tc.tyi, txi = tc.txi;
-    const int ty0 = tyi * 16, tx0 = txi * 16;
+
+  // ---- epilogue constants ---------------------------------------------------------------------------------------
+  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend, affine = bias || g.scale;
+  char* const scr = smem + R_OFF_SCR + wave * R_SCRB;
+  float* const red = reinterpret_cast<float*>(smem + R_OFF_RED);
+  const int tty8 = (g.MH + 7) >> 3;
+  const int ncol = wn * 32 + lr;
+  float bv = 0.f, sv = 1.f;
+  if (STATS) { bv = bias ? bias[ncol] : 0.f; sv = g.scale ? g.scale[ncol] : 1.f; }
+
+  auto flush_stats = [&](Tile tc, int par) __attribute__((always_inline)) {
+    // rows of the statistics buffer are numbered by 8x16-pixel tiles (jspsr_conv2d_stats_rows): pixel groups 0,1 are
+    // the upper half of this 16x16 tile, 2,3 the lower
+    if (tid < 256) {
+      const int half = tid >> 7, which = (tid >> 6) & 1, col = tid & 63;
+      const int row = 2 * tc.tyi + half;
+      if (row < tty8) {
+        const float* r0 = red + ((par * 4 + 2 * half) * 2 + which) * 64 + col;
+        stats[((size_t)((tc.bimg * tty8 + row) * ttx + tc.txi) * 2 + which) * 64 + col] = r0[0] + r0[2 * 64];
+      }
+    }
+  };
+
+  // 16-byte NHWC pieces go out through buffer descriptors over the batch image's slice: 32-bit offsets, and a pixel
+  // outside the written raster gets an offset that fails the range check (the store / addend load is dropped)
+  auto out_desc = [&](int bimg) {
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(out) + ((long long)bimg * g.OH * g.OW * g.out_cstride + g.out_coff + wn * 32) * 2;
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(b64), 0, 0xFFFFFF00u, 0x00020000);
+  };
+  auto add_desc = [&](int bimg) {
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(g.addend) + ((long long)bimg * g.OH * g.OW * g.add_cstride + wn * 32) * 2;
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(b64), 0, g.addend ? 0xFFFFFF00u : 0u, 0x00020000);
+  };
+
+  // Statistics form: a lane holds channel `ncol` of 2 x 16 pixels (rows of the MFMA result)
+  auto epilogue_stats = [&](Tile tc, int par) __attribute__((always_inline)) {
+    const int ty0 = tc.tyi * 16, tx0 = tc.txi * 16;
+    const bool whole = ty0 + 16 <= g.MH && tx0 + 16 <= g.MW;      // wave-uniform: no pixel of the tile is outside
     if (stats) {
       float s = 0.f, q = 0.f;
-      if (ty0 + 16 <= g.MH && tx0 + 16 <= g.MW) {          // interior tile (wave-uniform): every row counts
+      if (whole) {
         f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};              // two rows per v_pk_add_f32 / v_pk_fma_f32
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -256,23 +299,15 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
         const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float o = acc[mi][e];
         if (affine) o = o * sv + bv;
-        if (relu_first) o = fmaxf(o, 0.f);
+        if (relu_first) o = relu_bits(o);
         *reinterpret_cast<__bf16*>(scr + row * R_SCRP + lr * 2) = (__bf16)o;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private scratch: program order is enough
-    // 16-byte NHWC pieces out through buffer descriptors over the batch image's slice: 32-bit offsets, and a pixel
-    // outside the written raster gets an offset that fails the range check (the store / addend load is dropped)
     const int c16 = lane & 3, prow = lane >> 2;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(out) + ((long long)bimg * g.OH * g.OW * g.out_cstride + g.out_coff + wn * 32) * 2, 0, 0xFFFFFF00u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t adrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(static_cast<const char*>(g.addend)) + ((long long)bimg * g.OH * g.OW * g.add_cstride + wn * 32) * 2, 0,
-        g.addend ? 0xFFFFFF00u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = out_desc(tc.bimg), adrsrc = add_desc(tc.bimg);
     // requests first (addend pieces, then the scratch rows), stores last: a load's result is never awaited with a
     // store of this wave in flight
-    using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
     unsigned ooff[4], aoff[4];
-    const bool whole = ty0 + 16 <= g.MH && tx0 + 16 <= g.MW;      // wave-uniform: no pixel of the tile is outside
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int dy = wm * 4 + j;                              // tile row of scratch rows 16 j .. 16 j + 15
@@ -283,37 +318,95 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       aoff[j] = inside ? pix * (unsigned)(g.add_cstride * 2) + c16 * 16u : 0xFFFFFFF0u;
     }
     if (g.addend) {
-      u32x4v av[4];
+      u32x4 av[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) av[j] = __builtin_amdgcn_raw_buffer_load_b128(adrsrc, aoff[j], 0, 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint4 o = *reinterpret_cast<const uint4*>(scr + (j * 16 + prow) * R_SCRP + c16 * 16);
-        const unsigned pa[4] = {o.x, o.y, o.z, o.w};
-        u32x4v pr;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float lo = __uint_as_float(pa[i] << 16) + __uint_as_float(av[j][i] << 16);
-          float hi = __uint_as_float(pa[i] & 0xffff0000u) + __uint_as_float(av[j][i] & 0xffff0000u);
-          if (relu_last) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-          const __bf16 l = (__bf16)lo, h = (__bf16)hi;
-          pr[i] = (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(pr, orsrc, ooff[j], 0, 0);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(scr + (j * 16 + prow) * R_SCRP + c16 * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(add_bf16x8(o, av[j], relu_last), orsrc, ooff[j], 0, 0);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint4 o = *reinterpret_cast<const uint4*>(scr + (j * 16 + prow) * R_SCRP + c16 * 16);
-        const u32x4v ovv = {o.x, o.y, o.z, o.w};
-        __builtin_amdgcn_raw_buffer_store_b128(ovv, orsrc, ooff[j], 0, 0);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(scr + (j * 16 + prow) * R_SCRP + c16 * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[j], 0, 0);
       }
     }
   };
-  const bool late = wave >= 4;
+
+  // Plain form (operands swapped): lane (lr, lh) holds, of pixel 32 mi + lr of this wave's 64, the channels
+  // (e & 3) + 8 (e >> 2) + 4 lh of this wave's 32.  Groups of four go to bf16 pairs; v_permlane32_swap hands the lower
+  // half-wave the upper one's group 2 j (channels 8 j + 4 .. 8 j + 7) in exchange for its own group 2 j + 1: the lower
+  // half-wave then stores channels 0-7 and 16-23 of its pixel, the upper one 8-15 and 24-31, 16 bytes each.
+  auto epilogue_plain = [&](Tile tc) __attribute__((always_inline)) {
+    const int ty0 = tc.tyi * 16, tx0 = tc.txi * 16;
+    const bool whole = ty0 + 16 <= g.MH && tx0 + 16 <= g.MW;
+    const __amdgpu_buffer_rsrc_t orsrc = out_desc(tc.bimg), adrsrc = add_desc(tc.bimg);
+    unsigned ooff[2], aoff[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int R = wm * 64 + mi * 32 + lr, dy = R >> 4;
+      const int y = ty0 + dy, x = tx0 + ((R + R_ROT * dy) & 15);
+      const bool inside = whole || (y < g.MH && x < g.MW);
+      const unsigned pix = (unsigned)(y * g.OW + x);
+      ooff[mi] = inside ? pix * (unsigned)(g.out_cstride * 2) + lh * 16u : 0xFFFFFFF0u;
+      aoff[mi] = inside ? pix * (unsigned)(g.add_cstride * 2) + lh * 16u : 0xFFFFFFF0u;
+    }
+    u32x4 av[2][2];
+    if (g.addend) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) av[mi][h] = __builtin_amdgcn_raw_buffer_load_b128(adrsrc, aoff[mi], h * 32, 0);
+    }
+    if (relu_first) {      // wave-uniform
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][e] = relu_bits(acc[mi][e]);
+    }
+    unsigned d[2][8];      // bf16 pairs: d[mi][2 q], d[mi][2 q + 1] = group q (four channels) of pixel block mi
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) d[mi][e >> 1] = pack_bf16(acc[mi][e], acc[mi][e + 1]);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      // swap (group 0 | 1) and (group 2 | 3) between the half-waves
+#pragma unroll
+      for (int q = 0; q < 4; q += 2)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const auto r = __builtin_amdgcn_permlane32_swap(d[mi][2 * q + w], d[mi][2 * q + 2 + w], false, false);
+          d[mi][2 * q + w] = r[0];
+          d[mi][2 * q + 2 + w] = r[1];
+        }
+      // now this lane holds [d0 d1 d2 d3] = channels 8 lh + 0..7 and [d4 d5 d6 d7] = channels 16 + 8 lh + 0..7
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 o = {d[mi][4 * h], d[mi][4 * h + 1], d[mi][4 * h + 2], d[mi][4 * h + 3]};
+        if (g.addend) o = add_bf16x8(o, av[mi][h], relu_last);
+        __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[mi], h * 32, 0);
+      }
+    }
+  };
+  auto epilogue = [&](Tile tc, int par) __attribute__((always_inline)) {
+    if constexpr (STATS) epilogue_stats(tc, par); else epilogue_plain(tc);
+  };
+
+  // Waves w and w + 4 share a SIMD.  Run in lockstep they would both be in their MFMA phase, then both in their
+  // epilogue, and the matrix pipe would idle through every epilogue.  So waves 4-7 run HALF A TILE BEHIND: in the period
+  // of tile t (between two barriers) waves 0-3 multiply tile t (and request tile t + G's patch) and then write tile t
+  // out, while waves 4-7 first write out their part of tile t - G (accumulators kept across the barrier) and then
+  // multiply tile t.  Statistics of a tile are therefore complete one period late: three parities of the fold buffer,
+  // folded two periods after the tile.
   int t = v, it = 0;
   Tile tcur{(v / ttx) / tty, (v / ttx) % tty, v % ttx}, tprev = tcur, tprev2 = tcur, tnext = advance(tcur);
-  if (t < ntiles) issue_patch(tcur, 0);
+  if (t < ntiles) {
+    const PatchSrc p0 = patch_src(tcur);
+    issue_patch(p0, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef K2R_STAMPS      // lab build: cycles per phase, printed by waves 0 and 4 of workgroup 0 (tools/lab/build_k2r_variants.sh)
   unsigned long long st_bar = 0, st_pre = 0, st_mfma = 0, st_vm = 0, st_post = 0, s0, s1;
@@ -332,17 +425,21 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     K2R_STAMP(st_bar);
-    if (stats && it > 1) flush_stats(tprev2, (it - 2) % 3);
+    if (STATS && stats && it > 1) flush_stats(tprev2, (it - 2) % 3);
+    // Waves 0-3 request their pieces of the next patch before multiplying, waves 4-7 after writing their previous tile
+    // out: either way a whole tap loop lies between the request and the wait.
+    const bool more = t + G < ntiles;
+    const PatchSrc nxt = patch_src(tnext);
     if (late) {
       if (it > 0) epilogue(tprev, (it - 1) % 3);
-      if (t + G < ntiles) issue_patch(tnext, buf ^ 1);        // lands during this wave's MFMA phase
-    } else if (t + G < ntiles) {
-      issue_patch(tnext, buf ^ 1);
+      if (more) issue_patch(nxt, buf ^ 1);
+    } else if (more) {
+      issue_patch(nxt, buf ^ 1);
     }
     K2R_STAMP(st_pre);
     mfma_tile(buf);
     K2R_STAMP(st_mfma);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the DMA pieces issued above (long landed); no store is younger
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the pieces requested above (long landed); no store is younger
     K2R_STAMP(st_vm);
     if (!late) epilogue(tcur, it % 3);
     tprev2 = tprev; tprev = tcur; tcur = tnext; tnext = advance(tnext);
@@ -354,18 +451,31 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
            st_bar / it, st_pre / it, st_mfma / it, st_vm / it, st_post / it);
 #endif
   if (late && it > 0) epilogue(tprev, (it - 1) % 3);
-  if (stats && it > 0) {
+  if (STATS && stats && it > 0) {
     __syncthreads();
     if (it > 1) flush_stats(tprev2, (it - 2) % 3);
     flush_stats(tprev, (it - 1) % 3);
   }
 }
 
+template <int SIGN, bool STATS>
+void launch_k2r(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, int ntiles, int grid,
+                hipStream_t s) {
+  constexpr int lds = STATS ? R_LDS_STATS : R_LDS_PLAIN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<SIGN, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv64_resident_kernel<SIGN, STATS>), dim3(grid), dim3(R_NTH), lds, s, static_cast<const __bf16*>(in),
+                     static_cast<const __bf16*>(wgt), bias, static_cast<__bf16*>(out), stats, g, ntiles);
+}
+
 }  // namespace
 
 namespace jspsr {
 
-bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const void* out) {
+bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const float* bias, const void* out) {
   static const int enabled = [] { const char* e = getenv("JSPSR_CONV_RESIDENT"); return e ? atoi(e) : 1; }();
   if (!enabled) return false;
   if (g.Cin != 64 || g.Cout != 64 || g.nty != 3 || g.ntx != 3 || g.KH != 3 || g.KW != 3) return false;
@@ -374,6 +484,7 @@ bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, cons
   if (g.in_cstride % 8 || g.in_coff % 8 || g.out_cstride % 8 || g.out_coff % 8) return false;
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;
+  if ((g.scale && !aligned16(g.scale)) || (bias && !aligned16(bias))) return false;    // float4 loads of 4 channels
   if ((long long)(g.IW + 20) * 20 * g.in_cstride * 2 >= 0x7fffffffLL) return false;    // 32-bit offsets inside a patch
   if ((long long)g.OH * g.OW * g.out_cstride * 2 >= 0xF0000000LL || (long long)g.OH * g.OW * g.add_cstride * 2 >= 0xF0000000LL)
     return false;                                                                       // ... and inside one image of the result
@@ -391,16 +502,15 @@ int launch_conv64_resident(const void* in, const void* wgt, const float* bias, v
     hipDeviceProp_t p;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail((int)hipErrorInvalidDevice, "conv: device query failed");
     ncu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
   }
   const int grid = ntiles < ncu ? ntiles : ncu;
-  if (g.sign > 0)
-    hipLaunchKernelGGL(conv64_resident_kernel<1>, dim3(grid), dim3(R_NTH), R_LDS, s, static_cast<const __bf16*>(in),
-                       static_cast<const __bf16*>(wgt), bias, static_cast<__bf16*>(out), stats, g, ntiles);
-  else
-    hipLaunchKernelGGL(conv64_resident_kernel<-1>, dim3(grid), dim3(R_NTH), R_LDS, s, static_cast<const __bf16*>(in),
-                       static_cast<const __bf16*>(wgt), bias, static_cast<__bf16*>(out), stats, g, ntiles);
+  if (stats || bias || g.scale) {      // per-channel work: the lane-per-channel form
+    if (g.sign > 0) launch_k2r<1, true>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else launch_k2r<-1, true>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+  } else {
+    if (g.sign > 0) launch_k2r<1, false>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else launch_k2r<-1, false>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+  }
   return check_launch("conv64_resident");
 }
 

@@ -52,7 +52,7 @@ struct ConvGeom {
 };
 
 // K2r (conv64.hip): 3x3 64->64 unit-stride bf16 conv / data gradient, weights resident in registers
-bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const void* out);
+bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const float* bias, const void* out);
 int launch_conv64_resident(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g,
                            hipStream_t s);
 

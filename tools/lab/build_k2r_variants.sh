@@ -5,11 +5,12 @@ set -e
 cd "$(dirname "$0")/../../jspsr_amd/csrc"
 make -s -j6
 for la in "$@"; do
-  extra=""
-  if [ "$la" = "stamps" ]; then extra="-DK2R_STAMPS"; la=4; fi      # per-phase cycle counters printed by two waves
+  extra=""; name=""
+  if [ "$la" = "stamps" ]; then extra="-DK2R_STAMPS"; la=4; name=lab_k2r_stamps; fi      # per-phase cycle counters printed by two waves
+  case "$la" in e*) extra="-DK2R_EARLY=${la#e}"; name=lab_k2r_$la; la=4;; esac       # e<N>: pieces requested by each of waves 0-3
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DK2R_LA=$la $extra -c conv64.hip -o _obj/conv64_la$la.o
   objs=$(ls _obj/*.o | grep -v "conv64")
-  name=lab_k2r_la$la; [ -n "$extra" ] && name=lab_k2r_stamps
+  [ -z "$name" ] && name=lab_k2r_la$la
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/$name.so $objs _obj/conv64_la$la.o
   rm _obj/conv64_la$la.o
 done
