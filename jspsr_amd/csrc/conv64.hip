@@ -42,11 +42,20 @@ constexpr int R_PITCH = 144;                              // LDS bytes per patch
 constexpr int R_PPP = 7;                                  // pixels per DMA piece: 7 x 144 = 1008 B = 63 lanes x 16 B
 constexpr int R_PIECEB = R_PPP * R_PITCH;
 constexpr int R_PIECES = (R_NPIX + R_PPP - 1) / R_PPP;    // 47 pieces per patch
-#ifndef K2R_EARLY
-#define K2R_EARLY 8     // pieces per patch requested by each of waves 0-3; waves 4-7 share the rest (lab: -DK2R_EARLY=n)
+// Who requests the pieces, and when.  Waves 0-3 ("early") multiply the tile in the first half of a period, waves 4-7 in
+// the second (after writing their previous tile out).  Measured on one box (tools/lab/build_k2r_variants.sh o<order>e<n>):
+//   plain kernel: early waves request AFTER their tap loop and epilogue, 6 pieces each: 1145 TF/s (before the loop: 980)
+//   statistics kernel (long LDS epilogue): early waves request BEFORE their tap loop, 8 pieces each: 880 (after: 750)
+#ifdef K2R_ORDER
+constexpr int order_of(bool) { return K2R_ORDER; }
+#else
+constexpr int order_of(bool stats) { return stats ? 0 : 2; }
 #endif
-constexpr int R_PE = K2R_EARLY, R_PL = (R_PIECES - 4 * R_PE + 3) / 4;      // waves 4-7 have the longer pre-MFMA part (an epilogue)
-constexpr int R_PIT = R_PE > R_PL ? R_PE : R_PL;
+#ifdef K2R_EARLY
+constexpr int early_pieces(bool) { return K2R_EARLY; }
+#else
+constexpr int early_pieces(bool stats) { return stats ? 8 : 6; }
+#endif
 constexpr int R_PATCHB = R_PIECES * R_PIECEB + 16;        // 47392 B per patch buffer (+16: lane 63 of the last piece)
 constexpr int R_SCRP = 80;                                // scratch row pitch: 64 B of channels + 16
 constexpr int R_SCRB = 64 * R_SCRP;                       // per wave
@@ -102,6 +111,8 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;      // LDS byte address of the dynamic segment
   const int v = xcd_contiguous(blockIdx.x, G);
   const bool late = wave >= 4;
+  constexpr int ORDER = order_of(STATS), R_PE = early_pieces(STATS), R_PL = (R_PIECES - 4 * R_PE + 3) / 4;
+  constexpr int R_PIT = R_PE > R_PL ? R_PE : R_PL;      // pieces per wave: waves 0-3 R_PE each, waves 4-7 share the rest
 
   // ---- weights: 36 fragments (9 taps x 4 sub-steps) of this wave's 32 output channels, once ------------------------
   bf16x8 breg[9][4];
@@ -430,6 +441,7 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     // out: either way a whole tap loop lies between the request and the wait.
     const bool more = t + G < ntiles;
     const PatchSrc nxt = patch_src(tnext);
+    if constexpr (ORDER == 0) {
     if (late) {
       if (it > 0) epilogue(tprev, (it - 1) % 3);
       if (more) issue_patch(nxt, buf ^ 1);
@@ -442,6 +454,23 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the pieces requested above (long landed); no store is younger
     K2R_STAMP(st_vm);
     if (!late) epilogue(tcur, it % 3);
+    } else {
+    // waves 0-3 multiply FIRST (their SIMD partners are in their epilogue), then request their pieces and write out
+    if (late) {
+      if (it > 0) epilogue(tprev, (it - 1) % 3);
+      if (more) issue_patch(nxt, buf ^ 1);
+    }
+    K2R_STAMP(st_pre);
+    mfma_tile(buf);
+    K2R_STAMP(st_mfma);
+    if (!late) {
+      if (ORDER == 1 && more) issue_patch(nxt, buf ^ 1);
+      epilogue(tcur, it % 3);
+      if (ORDER == 2 && more) issue_patch(nxt, buf ^ 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces (and, in waves 0-3, its stores)
+    K2R_STAMP(st_vm);
+    }
     tprev2 = tprev; tprev = tcur; tcur = tnext; tnext = advance(tnext);
     K2R_STAMP(st_post);
   }
