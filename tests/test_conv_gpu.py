@@ -142,9 +142,9 @@ def test_conv_16x16_tile_path(dtype, B, H, W, Cin, Cout):
     assert _relerr(_nchw(dx.float()), xx.grad) < tol
 
 
-@pytest.mark.parametrize("B,H,W", [(4, 256, 256), (5, 232, 250), (1, 512, 520)])
+@pytest.mark.parametrize("B,H,W", [(4, 256, 256), (5, 232, 250), (1, 512, 520), (2, 256, 256), (3, 200, 216)])
 def test_conv_resident_weights_path(B, H, W):
-    """3x3 64->64 bf16 convs on >= 1024 16x16 tiles run K2r (conv64.hip: weights in registers, patches by LDS-DMA,
+    """3x3 64->64 bf16 convs on >= 512 16x16 tiles run K2r (conv64.hip: weights in registers, patches by LDS-DMA,
     zero padding from the descriptor's range check): forward with the BatchNorm partial statistics on ragged rasters,
     every epilogue form (bias + ReLU; scale + addend + ReLU), channel slices on both sides, and the data gradient
     (reversed tap walk) with an addend."""
