@@ -20,12 +20,15 @@
 //     one barrier per tile (patch t+1 landed / everyone is done with patch t-1);
 //   * waves 4-7 run half a tile behind waves 0-3 (their SIMD partners): one wave of each SIMD is on the matrix pipe
 //     while the other writes its previous tile out;
-//   * two epilogues.  Without statistics or a per-channel scale / bias (data gradient, plain convs) the MFMA operands are SWAPPED, so a lane holds
-//     sixteen CHANNELS of one pixel: v_cvt_pk_bf16_f32 pairs them, v_permlane32_swap joins the two half-waves' groups
-//     of four into 16-byte NHWC pieces, and the tile goes out from registers -- no LDS, ~40 vector instructions.  With
+//   * two epilogues.  Without statistics (data gradient, plain and bias / scale convs) the MFMA operands are SWAPPED, so
+//     a lane holds sixteen CHANNELS of one pixel: v_cvt_pk_bf16_f32 pairs them, v_permlane32_swap joins the two
+//     half-waves' groups of four into 16-byte NHWC pieces, and the tile goes out from registers -- no LDS, ~40 vector
+//     instructions (+ 32 fused multiply-adds and eight float4 parameter loads for a per-channel scale / bias).  With
 //     BatchNorm statistics (training forward) a lane holds one channel of sixteen pixels, the per-channel sums are
 //     in-lane adds, and the tile is transposed through a wave-private LDS scratch; the statistics of a tile are folded
-//     across the four pixel groups two barriers later.
+//     across the four pixel groups two barriers later.  (A register form of the statistics -- a halving DPP /
+//     ds_swizzle / v_permlane16_swap butterfly over the 32 lanes of a half-wave -- was built and measured 5-10 %
+//     slower than the LDS form: 730-830 vs 845-905 TF/s.)
 // Out-of-image patch pixels fail the buffer descriptor's range check and land as zeros (the conv's zero padding).
 #include "conv_igemm.h"
 
@@ -63,6 +66,8 @@ constexpr int R_OFF_SCR = 2 * R_PATCHB;
 constexpr int R_OFF_RED = R_OFF_SCR + 8 * R_SCRB;         // [3][4][2][64] floats
 constexpr int R_LDS_STATS = R_OFF_RED + 3 * 4 * 2 * 64 * 4;
 constexpr int R_LDS_PLAIN = 2 * R_PATCHB;
+constexpr int R_OFF_PAR = 2 * R_PATCHB;                   // affine kernel: [2][64] floats, per-channel scale | bias
+constexpr int R_LDS_AFFINE = R_OFF_PAR + 2 * 64 * 4;
 #ifndef K2R_LA
 #define K2R_LA 4      // patch fragments requested ahead of their MFMA (lab builds: -DK2R_LA=n)
 #endif
@@ -98,10 +103,11 @@ __device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b, bool relu) {
   return r;
 }
 
-template <int SIGN, bool STATS>
+template <int SIGN, int MODE>      // MODE 0: plain, 1: + BatchNorm statistics, 2: + per-channel scale / bias
 __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt,
                                                                   const float* __restrict__ bias, __bf16* __restrict__ out,
                                                                   float* __restrict__ stats, ConvGeom g, int ntiles) {
+  constexpr bool STATS = MODE == 1, AFFINE = MODE == 2;
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = (wave >> 1) & 3, wn = wave & 1;
@@ -230,13 +236,11 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   };
 
   // ---- epilogue constants ---------------------------------------------------------------------------------------
-  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend, affine = bias || g.scale;
+  const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend;
   char* const scr = smem + R_OFF_SCR + wave * R_SCRB;
   float* const red = reinterpret_cast<float*>(smem + R_OFF_RED);
-  const int tty8 = (g.MH + 7) >> 3;
   const int ncol = wn * 32 + lr;
-  float bv = 0.f, sv = 1.f;
-  if (STATS) { bv = bias ? bias[ncol] : 0.f; sv = g.scale ? g.scale[ncol] : 1.f; }
+  const int tty8 = (g.MH + 7) >> 3;
 
   auto flush_stats = [&](Tile tc, int par) __attribute__((always_inline)) {
     // rows of the statistics buffer are numbered by 8x16-pixel tiles (jspsr_conv2d_stats_rows): pixel groups 0,1 are
@@ -308,9 +312,7 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float o = acc[mi][e];
-        if (affine) o = o * sv + bv;
-        if (relu_first) o = relu_bits(o);
+        const float o = acc[mi][e];
         *reinterpret_cast<__bf16*>(scr + row * R_SCRP + lr * 2) = (__bf16)o;
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private scratch: program order is enough
@@ -346,11 +348,11 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     }
   };
 
-  // Plain form (operands swapped): lane (lr, lh) holds, of pixel 32 mi + lr of this wave's 64, the channels
+  // Epilogue (MFMA operands swapped: rows = channels): lane (lr, lh) holds, of pixel 32 mi + lr of this wave's 64, the channels
   // (e & 3) + 8 (e >> 2) + 4 lh of this wave's 32.  Groups of four go to bf16 pairs; v_permlane32_swap hands the lower
   // half-wave the upper one's group 2 j (channels 8 j + 4 .. 8 j + 7) in exchange for its own group 2 j + 1: the lower
   // half-wave then stores channels 0-7 and 16-23 of its pixel, the upper one 8-15 and 24-31, 16 bytes each.
-  auto epilogue_plain = [&](Tile tc) __attribute__((always_inline)) {
+  auto epilogue_regs = [&](Tile tc) __attribute__((always_inline)) {
     const int ty0 = tc.tyi * 16, tx0 = tc.txi * 16;
     const bool whole = ty0 + 16 <= g.MH && tx0 + 16 <= g.MW;
     const __amdgpu_buffer_rsrc_t orsrc = out_desc(tc.bimg), adrsrc = add_desc(tc.bimg);
@@ -370,6 +372,17 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int h = 0; h < 2; ++h) av[mi][h] = __builtin_amdgcn_raw_buffer_load_b128(adrsrc, aoff[mi], h * 32, 0);
+    }
+    if constexpr (AFFINE) {      // per-channel scale / bias of this lane's sixteen channels, from the table the prologue put in LDS
+      const float* tab = reinterpret_cast<const float*>(smem + R_OFF_PAR) + wn * 32 + 4 * lh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4v s4 = *reinterpret_cast<const f32x4v*>(tab + 8 * q), b4 = *reinterpret_cast<const f32x4v*>(tab + 64 + 8 * q);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[mi][4 * q + i] = acc[mi][4 * q + i] * s4[i] + b4[i];
+      }
     }
     if (relu_first) {      // wave-uniform
 #pragma unroll
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     }
   };
   auto epilogue = [&](Tile tc, int par) __attribute__((always_inline)) {
-    if constexpr (STATS) epilogue_stats(tc, par); else epilogue_plain(tc);
+    if constexpr (STATS) epilogue_stats(tc, par); else epilogue_regs(tc);
   };
 
   // Waves w and w + 4 share a SIMD.  Run in lockstep they would both be in their MFMA phase, then both in their
@@ -412,6 +425,9 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   // out, while waves 4-7 first write out their part of tile t - G (accumulators kept across the barrier) and then
   // multiply tile t.  Statistics of a tile are therefore complete one period late: three parities of the fold buffer,
   // folded two periods after the tile.
+  if constexpr (AFFINE) {      // absent scale -> 1, absent bias -> 0; visible to every wave after the first barrier of the loop
+    if (tid < 128) reinterpret_cast<float*>(smem + R_OFF_PAR)[tid] = tid < 64 ? (g.scale ? g.scale[tid] : 1.f) : (bias ? bias[tid - 64] : 0.f);
+  }
   int t = v, it = 0;
   Tile tcur{(v / ttx) / tty, (v / ttx) % tty, v % ttx}, tprev = tcur, tprev2 = tcur, tnext = advance(tcur);
   if (t < ntiles) {
@@ -487,16 +503,16 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   }
 }
 
-template <int SIGN, bool STATS>
+template <int SIGN, int MODE>
 void launch_k2r(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, int ntiles, int grid,
                 hipStream_t s) {
-  constexpr int lds = STATS ? R_LDS_STATS : R_LDS_PLAIN;
+  constexpr int lds = MODE == 1 ? R_LDS_STATS : (MODE == 2 ? R_LDS_AFFINE : R_LDS_PLAIN);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<SIGN, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<SIGN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv64_resident_kernel<SIGN, STATS>), dim3(grid), dim3(R_NTH), lds, s, static_cast<const __bf16*>(in),
+  hipLaunchKernelGGL((conv64_resident_kernel<SIGN, MODE>), dim3(grid), dim3(R_NTH), lds, s, static_cast<const __bf16*>(in),
                      static_cast<const __bf16*>(wgt), bias, static_cast<__bf16*>(out), stats, g, ntiles);
 }
 
@@ -533,12 +549,15 @@ int launch_conv64_resident(const void* in, const void* wgt, const float* bias, v
     ncu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }
   const int grid = ntiles < ncu ? ntiles : ncu;
-  if (stats || bias || g.scale) {      // per-channel work: the lane-per-channel form
-    if (g.sign > 0) launch_k2r<1, true>(in, wgt, bias, out, stats, g, ntiles, grid, s);
-    else launch_k2r<-1, true>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+  const int mode = stats ? 1 : ((bias || g.scale) ? 2 : 0);      // the C ABI refuses statistics together with bias / scale
+  if (g.sign > 0) {
+    if (mode == 0) launch_k2r<1, 0>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else if (mode == 1) launch_k2r<1, 1>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else launch_k2r<1, 2>(in, wgt, bias, out, stats, g, ntiles, grid, s);
   } else {
-    if (g.sign > 0) launch_k2r<1, false>(in, wgt, bias, out, stats, g, ntiles, grid, s);
-    else launch_k2r<-1, false>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    if (mode == 0) launch_k2r<-1, 0>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else if (mode == 1) launch_k2r<-1, 1>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else launch_k2r<-1, 2>(in, wgt, bias, out, stats, g, ntiles, grid, s);
   }
   return check_launch("conv64_resident");
 }

@@ -42,7 +42,8 @@ def main():
     only = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) >= 0 else None      # shape index (-1: all)
     dts = (torch.bfloat16,) if len(sys.argv) > 3 and sys.argv[3] == "bf16" else (torch.float32, torch.bfloat16)
     ours_only = len(sys.argv) > 4
-    with_stats = len(sys.argv) > 5      # forward: also the BatchNorm partial statistics from the epilogue
+    with_stats = len(sys.argv) > 5 and sys.argv[5] == "stats"     # forward: also the BatchNorm partial statistics from the epilogue
+    with_bias = len(sys.argv) > 5 and sys.argv[5] == "bias"       # forward: bias + ReLU epilogue (the BN-free units)
     for dtype in dts:
         for si, (B, H, W, Ci, Co, k, s) in enumerate(SHAPES):
             if only is not None and si != only:
@@ -54,7 +55,8 @@ def main():
             flops = 2.0 * B * OH * OW * Co * Ci * k * k
             if which == "fwd":
                 wp = K.pack_weight(w, 0, Ci, dtype)
-                t = timeit(lambda: K.conv2d_forward(x, wp, None, s, pad, stats=with_stats))
+                b = torch.randn(Co, device="cuda") if with_bias else None
+                t = timeit(lambda: K.conv2d_forward(x, wp, b, s, pad, relu=with_bias, stats=with_stats))
                 xc = x.permute(0, 3, 1, 2)  # channels_last view
                 wc = w.to(dtype).contiguous(memory_format=torch.channels_last)
                 tm = float("nan") if ours_only else timeit(lambda: F.conv2d(xc, wc, None, s, pad))
