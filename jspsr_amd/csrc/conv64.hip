@@ -23,7 +23,7 @@
 //   * two epilogues.  Without statistics (data gradient, plain and bias / scale convs) the MFMA operands are SWAPPED, so
 //     a lane holds sixteen CHANNELS of one pixel: v_cvt_pk_bf16_f32 pairs them, v_permlane32_swap joins the two
 //     half-waves' groups of four into 16-byte NHWC pieces, and the tile goes out from registers -- no LDS, ~40 vector
-//     instructions (+ 32 fused multiply-adds and eight float4 parameter loads for a per-channel scale / bias).  With
+//     instructions (+ 32 fused multiply-adds against a 512-byte LDS table for a per-channel scale / bias).  With
 //     BatchNorm statistics (training forward) a lane holds one channel of sixteen pixels, the per-channel sums are
 //     in-lane adds, and the tile is transposed through a wave-private LDS scratch; the statistics of a tile are folded
 //     across the four pixel groups two barriers later.  (A register form of the statistics -- a halving DPP /
@@ -529,7 +529,6 @@ bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, cons
   if (g.in_cstride % 8 || g.in_coff % 8 || g.out_cstride % 8 || g.out_coff % 8) return false;
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;
-  if ((g.scale && !aligned16(g.scale)) || (bias && !aligned16(bias))) return false;    // float4 loads of 4 channels
   if ((long long)(g.IW + 20) * 20 * g.in_cstride * 2 >= 0x7fffffffLL) return false;    // 32-bit offsets inside a patch
   if ((long long)g.OH * g.OW * g.out_cstride * 2 >= 0xF0000000LL || (long long)g.OH * g.OW * g.add_cstride * 2 >= 0xF0000000LL)
     return false;                                                                       // ... and inside one image of the result
