@@ -192,6 +192,38 @@ def test_conv_resident_weights_path(B, H, W):
     assert _relerr(_nchw(dx.float()), xx.grad.bfloat16().double() + res.double()) < 6e-3
 
 
+def test_conv_resident_kernels_overlap_on_two_streams():
+    """K2r is a persistent kernel (one workgroup per CU, most of the CU's LDS and registers) with no device-global state:
+    launches of its three modes queued on two streams at once -- as the step's branch streams do -- must give the bits of
+    the same launches run one after the other."""
+    K = _k()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(2, 256, 256, 64, generator=g).cuda().to(dtype) for _ in range(2)]
+    ws = [(torch.randn(64, 64, 3, 3, generator=g) / 24.0).cuda() for _ in range(2)]
+    bias = torch.randn(64, generator=g).cuda()
+    packs = [(K.pack_weight(w, 0, 64, dtype), K.pack_weight(w, 1, 64, dtype)) for w in ws]
+
+    def work(i):
+        y, st = K.conv2d_forward(xs[i], packs[i][0], None, 1, 1, stats=True)
+        z = K.conv2d_forward(y, packs[i][0], bias, 1, 1, relu=True)
+        return y, st, z, K.conv2d_dgrad(z, packs[i][1], (256, 256), 1, 1, addend=xs[i])
+
+    ref = [work(0), work(1)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = [None, None]
+    for rep in range(3):
+        for i, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                out[i] = work(i)
+        torch.cuda.synchronize()
+        for i in range(2):
+            for a, b in zip(out[i], ref[i]):
+                assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [
     (2, 64, 64, 64, 64),      # one tile pair
