@@ -307,6 +307,11 @@ int jspsr_metrics_forward(const float* pred, const float* gt, int H, int W, floa
 int jspsr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, jspsr_stream_t stream);
 
+/* The models' first step with every input (the reference hands them contiguous planar fp32 tensors, utils/utils.py:156-179;
+ * models/JSPSR.py:208-222 then feeds the stems): src (B,C,H,W) fp32 -> dst (B,H,W,c_pad) in `dtype`, channels last and
+ * zero-padded to c_pad (a multiple of 4 fp32 / 8 bf16 channels, >= C).  One pass; dst 16-byte aligned. */
+int jspsr_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int c_pad, jspsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

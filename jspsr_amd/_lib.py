@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("JSPSR_LAB_LIB") or os.path.join(_HERE, "lib", "libjspsr_hip.so")  # JSPSR_LAB_LIB: kernel-lab builds only
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lock = threading.Lock()
 _lib = None
@@ -63,6 +63,7 @@ SIGNATURES = {
     "jspsr_metrics_workspace_bytes": (ctypes.c_size_t, [c_i, c_i]),
     "jspsr_metrics_forward": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),
     "jspsr_adamw_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, c_p]),
+    "jspsr_nchw_to_nhwc": (c_i, [c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
 }
 
 

@@ -24,5 +24,5 @@ int check_launch(const char* what) {
 
 }  // namespace jspsr
 
-extern "C" int jspsr_abi_version(void) { return 11; }
+extern "C" int jspsr_abi_version(void) { return 12; }
 extern "C" const char* jspsr_last_error(void) { return jspsr::err_buf(); }

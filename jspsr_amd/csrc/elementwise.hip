@@ -793,3 +793,39 @@ extern "C" int jspsr_gate_backward_apply(int dtype, const void* dy, const float*
                                      static_cast<const T*>(dy), s_, davg, dmax, amax, static_cast<T*>(dx), g));
   return check_launch("gate_backward_apply");
 }
+
+// ---------------------------------------------------------------- boundary: planar fp32 -> NHWC activations
+// What the models do first with every input (utils/utils.py:156-179 hands them planar fp32 tensors): cast to the compute
+// dtype, put the channels last, zero-pad them to whole 16-byte chunks -- one pass instead of torch's cast + pad + copy.
+// A thread owns a pixel: its C plane reads are coalesced across the wave, its Cpad channels leave as 16-byte stores.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, long long HW,
+                                                          long long npix, int Cpad) {
+  constexpr int N = V<T>::N;
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+    const long long b = p / HW, q = p - b * HW;
+    const float* s = src + (size_t)b * C * HW + q;
+    T* d = dst + (size_t)p * Cpad;
+    for (int c0 = 0; c0 < Cpad; c0 += N) {
+      float f[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) f[i] = c0 + i < C ? s[(size_t)(c0 + i) * HW] : 0.f;
+      store_vec<T>(d + c0, f);
+    }
+  }
+}
+
+extern "C" int jspsr_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int c_pad,
+                                  jspsr_stream_t stream) {
+  if (dtype != JSPSR_F32 && dtype != JSPSR_BF16) return fail(JSPSR_EINVAL, "nchw_to_nhwc: dtype must be JSPSR_F32 or JSPSR_BF16");
+  const int vec = dtype == JSPSR_F32 ? 4 : 8;
+  if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || c_pad < C || c_pad % vec)
+    return fail(JSPSR_EINVAL, "nchw_to_nhwc: bad arguments (c_pad must be a multiple of %d and >= C)", vec);
+  if (!aligned4(src) || !aligned16(dst)) return fail(JSPSR_EALIGN, "nchw_to_nhwc: src must be 4-byte, dst 16-byte aligned");
+  const long long HW = (long long)H * W, npix = HW * B;
+  const long long want = (npix + 255) / 256;
+  const int blocks = (int)(want > 8192 ? 8192 : want);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(blocks), dim3(256), 0, s, src, static_cast<T*>(dst), C, HW, npix, c_pad));
+  return check_launch("nchw_to_nhwc");
+}

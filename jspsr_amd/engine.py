@@ -46,8 +46,11 @@ def from_nchw(x: torch.Tensor) -> torch.Tensor:
     """Boundary tensor (B,C,H,W) fp32 -> NHWC activations in the compute dtype, channel-padded."""
     _gpu(x)
     B, C, H, W = x.shape
-    x = x.reshape(B, H, W, 1) if C == 1 else x.permute(0, 2, 3, 1)
-    return ops.pad_channels(x.to(_compute_dtype), K.epc(_compute_dtype)).contiguous()
+    e = K.epc(_compute_dtype)
+    if x.dtype == torch.float32 and x.is_contiguous() and not (x.requires_grad and torch.is_grad_enabled()):
+        return K.nchw_to_nhwc(x, _compute_dtype, (C + e - 1) // e * e)      # cast + channels-last + pad in one launch
+    x = x.reshape(B, H, W, 1) if C == 1 else x.permute(0, 2, 3, 1)           # inputs that carry a gradient: torch ops
+    return ops.pad_channels(x.to(_compute_dtype), e).contiguous()
 
 
 def to_nchw_f32(x: torch.Tensor) -> torch.Tensor:

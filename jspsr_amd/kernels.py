@@ -331,3 +331,15 @@ def gate_backward_apply(dy, s, davg, dmax, amax):
                                              amax.data_ptr(), dx.data_ptr(), B, H * W, C, _stream()),
                "jspsr_gate_backward_apply")
     return dx
+
+
+def nchw_to_nhwc(x, dtype, c_pad):
+    """Boundary tensor (B,C,H,W) contiguous fp32 -> (B,H,W,c_pad) in `dtype`, channels last, zero-padded: one launch."""
+    if x.dtype != torch.float32 or not x.is_contiguous() or not x.is_cuda:
+        raise ValueError("nchw_to_nhwc: a contiguous fp32 CUDA tensor (B,C,H,W) is expected")
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, c_pad), dtype=dtype, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_nchw_to_nhwc(BF16 if dtype == torch.bfloat16 else F32, x.data_ptr(), out.data_ptr(),
+                                      B, C, H, W, c_pad, _stream()), "jspsr_nchw_to_nhwc")
+    return out

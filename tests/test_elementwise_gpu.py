@@ -124,3 +124,18 @@ def test_channel_gate(dtype, B, C, H, W):
     davg, dmax = torch.autograd.grad(s, (avg, mx), ds)
     dx = K.gate_backward_apply(dyd, s.detach().contiguous(), davg.contiguous(), dmax.contiguous(), amax)
     assert _rel(_nchw(dx), xr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(2, 1, 24, 40), (1, 3, 17, 33), (3, 15, 16, 16), (1, 19, 8, 24)])
+def test_boundary_conversion_nchw_to_nhwc(dtype, B, C, H, W):
+    """jspsr_nchw_to_nhwc (what engine.from_nchw does with every model input) == cast + channels-last + zero pad."""
+    from jspsr_amd import kernels as K
+    x = torch.randn(B, C, H, W, device="cuda")
+    e = K.epc(dtype)
+    cp = (C + e - 1) // e * e
+    y = K.nchw_to_nhwc(x, dtype, cp)
+    ref = torch.nn.functional.pad(x.permute(0, 2, 3, 1).to(dtype), (0, cp - C)).contiguous()
+    assert y.shape == ref.shape and torch.equal(y, ref)
+    with pytest.raises(Exception):
+        K.nchw_to_nhwc(x, dtype, C if C % e else C + 1)          # c_pad must be a whole number of 16-byte chunks
