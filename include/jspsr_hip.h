@@ -265,7 +265,7 @@ int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const 
  * gate_pool: avg[b,c], mx[b,c] over the npix pixels of image b, amax = smallest pixel index of the
  * max.  gate_scale: y = x * s[b,c].  Backward: ds[b,c] = sum_p dy*x (reduce), then
  * dx = dy*s + davg/npix + [p == amax] dmax (apply).  The C -> C/16 -> C MLP between pool and
- * scale works on B x C vectors and stays on the host side of the ABI. */
+ * scale works on B x C vectors: jspsr_gate_mlp_* below. */
 int jspsr_gate_pool(int dtype, const void* x, int B, long long npix, int C, float* avg, float* mx, int* amax,
                     void* workspace, jspsr_stream_t stream);
 int jspsr_gate_scale(int dtype, const void* x, const float* s, void* y, int B, long long npix, int C,
@@ -306,6 +306,18 @@ int jspsr_metrics_forward(const float* pred, const float* gt, int H, int W, floa
  * 4-byte aligned and share one offset from a 16-byte boundary (sub-ranges of four identically laid out buffers). */
 int jspsr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, jspsr_stream_t stream);
+
+/* The MLP between gate_pool and gate_scale (resnet_cbam.py:41-53: two bias-free 1x1 convs C -> Ch -> C shared by the
+ * average- and the max-pooled vector, ReLU between, Sigmoid of the sum): s[b,c] = sigmoid(W2 relu(W1 avg[b]) + W2 relu(W1
+ * mx[b])).  w1 (Ch, C), w2 (C, Ch) fp32 row-major; hid (B, 2, Ch) receives the two hidden vectors for the backward pass.
+ * Backward: from ds (B, C) the gradients of avg, mx (B, C) and of the two weights (summed over the batch in image order);
+ * workspace of jspsr_gate_mlp_backward_workspace_bytes.  Needs (C + 2 Ch) * 4 bytes <= 64 KiB. */
+int jspsr_gate_mlp_forward(const float* avg, const float* mx, const float* w1, const float* w2, int B, int C, int Ch,
+                           float* s, float* hid, jspsr_stream_t stream);
+size_t jspsr_gate_mlp_backward_workspace_bytes(int B, int C, int Ch);
+int jspsr_gate_mlp_backward(const float* ds, const float* s, const float* hid, const float* avg, const float* mx,
+                            const float* w1, const float* w2, int B, int C, int Ch, float* davg, float* dmax, float* dw1,
+                            float* dw2, void* workspace, jspsr_stream_t stream);
 
 /* The models' first step with every input (the reference hands them contiguous planar fp32 tensors, utils/utils.py:156-179;
  * models/JSPSR.py:208-222 then feeds the stems): src (B,C,H,W) fp32 -> dst (B,H,W,c_pad) in `dtype`, channels last and

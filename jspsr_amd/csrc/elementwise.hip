@@ -829,3 +829,131 @@ extern "C" int jspsr_nchw_to_nhwc(int dtype, const float* src, void* dst, int B,
   DISPATCH(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(blocks), dim3(256), 0, s, src, static_cast<T*>(dst), C, HW, npix, c_pad));
   return check_launch("nchw_to_nhwc");
 }
+
+// ---------------------------------------------------------------- ChannelAttention: the C -> C/16 -> C MLP on (B, C) vectors
+// s[b] = sigmoid(W2 relu(W1 avg[b]) + W2 relu(W1 mx[b])) (resnet_cbam.py:41-53; both 1x1 convs without bias), forward
+// and backward as three launches instead of the ~45 tiny library kernels torch needs for it (matrix products of 8 x C
+// vectors, ReLU, Sigmoid and their autograd) -- on the step's critical path in front of every decoder conv.
+// hid[b][0|1][j] keeps relu(W1 avg), relu(W1 mx) for the backward pass.  Sums run in a fixed order: reproducible.
+constexpr int GM_T = 256;
+
+__global__ __launch_bounds__(GM_T) void gate_mlp_fwd_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
+                                                           const float* __restrict__ w1, const float* __restrict__ w2, int C, int Ch,
+                                                           float* __restrict__ s, float* __restrict__ hid) {
+  extern __shared__ float gm_lds[];       // [Ch] h_avg + h_max
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* a = avg + (size_t)b * C;
+  const float* m = mx + (size_t)b * C;
+  for (int j = wave; j < Ch; j += GM_T / 64) {          // one wave per hidden unit: two C-long dot products
+    const float* w = w1 + (size_t)j * C;
+    float da = 0.f, dm = 0.f;
+    for (int c = lane; c < C; c += 64) { const float wv = w[c]; da += wv * a[c]; dm += wv * m[c]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { da += __shfl_xor(da, d, 64); dm += __shfl_xor(dm, d, 64); }
+    if (lane == 0) {
+      const float ha = fmaxf(da, 0.f), hm = fmaxf(dm, 0.f);
+      hid[((size_t)b * 2 + 0) * Ch + j] = ha;
+      hid[((size_t)b * 2 + 1) * Ch + j] = hm;
+      gm_lds[j] = ha + hm;                              // W2 is linear and has no bias: W2 ha + W2 hm = W2 (ha + hm)
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += GM_T) {
+    const float* w = w2 + (size_t)c * Ch;
+    float z = 0.f;
+    for (int j = 0; j < Ch; ++j) z += w[j] * gm_lds[j];
+    s[(size_t)b * C + c] = 1.f / (1.f + expf(-z));
+  }
+}
+
+// per image: dz = ds s (1 - s); dh = W2^T dz, masked by the two ReLUs; davg = W1^T dh_a, dmax = W1^T dh_m.
+// dzs[b][c] and dhs[b][0|1][j] are kept for the weight-gradient launch.
+__global__ __launch_bounds__(GM_T) void gate_mlp_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ s,
+                                                           const float* __restrict__ hid, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, int C, int Ch, float* __restrict__ davg,
+                                                           float* __restrict__ dmax, float* __restrict__ dzs, float* __restrict__ dhs) {
+  extern __shared__ float gm_lds[];       // [C] dz, then [2][Ch] dh
+  float* dz = gm_lds;
+  float* dh = gm_lds + C;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int c = tid; c < C; c += GM_T) {
+    const float sv = s[(size_t)b * C + c], v = ds[(size_t)b * C + c] * sv * (1.f - sv);
+    dz[c] = v;
+    dzs[(size_t)b * C + c] = v;
+  }
+  __syncthreads();
+  for (int j = wave; j < Ch; j += GM_T / 64) {          // dh[j] = sum_c w2[c][j] dz[c]
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += w2[(size_t)c * Ch + j] * dz[c];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) {
+      const float da = hid[((size_t)b * 2 + 0) * Ch + j] > 0.f ? acc : 0.f, dm = hid[((size_t)b * 2 + 1) * Ch + j] > 0.f ? acc : 0.f;
+      dh[j] = da; dh[Ch + j] = dm;
+      dhs[((size_t)b * 2 + 0) * Ch + j] = da;
+      dhs[((size_t)b * 2 + 1) * Ch + j] = dm;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += GM_T) {
+    float ga = 0.f, gm = 0.f;
+    for (int j = 0; j < Ch; ++j) { const float wv = w1[(size_t)j * C + c]; ga += wv * dh[j]; gm += wv * dh[Ch + j]; }
+    davg[(size_t)b * C + c] = ga;
+    dmax[(size_t)b * C + c] = gm;
+  }
+}
+
+// dw2[c][j] = sum_b dz[b][c] (ha + hm)[b][j];  dw1[j][c] = sum_b dh_a[b][j] avg[b][c] + dh_m[b][j] mx[b][c]  (b in order)
+__global__ __launch_bounds__(GM_T) void gate_mlp_wgrad_kernel(const float* __restrict__ dzs, const float* __restrict__ dhs,
+                                                             const float* __restrict__ hid, const float* __restrict__ avg,
+                                                             const float* __restrict__ mx, int B, int C, int Ch,
+                                                             float* __restrict__ dw1, float* __restrict__ dw2) {
+  const long long n = (long long)C * Ch;
+  for (long long i = blockIdx.x * (long long)GM_T + threadIdx.x; i < 2 * n; i += (long long)gridDim.x * GM_T) {
+    if (i < n) {                                        // dw1, [Ch][C]: consecutive threads -> consecutive c
+      const int j = (int)(i / C), c = (int)(i - (long long)j * C);
+      float g = 0.f;
+      for (int b = 0; b < B; ++b)
+        g += dhs[((size_t)b * 2 + 0) * Ch + j] * avg[(size_t)b * C + c] + dhs[((size_t)b * 2 + 1) * Ch + j] * mx[(size_t)b * C + c];
+      dw1[i] = g;
+    } else {                                            // dw2, [C][Ch]
+      const long long k = i - n;
+      const int c = (int)(k / Ch), j = (int)(k - (long long)c * Ch);
+      float g = 0.f;
+      for (int b = 0; b < B; ++b) g += dzs[(size_t)b * C + c] * (hid[((size_t)b * 2 + 0) * Ch + j] + hid[((size_t)b * 2 + 1) * Ch + j]);
+      dw2[k] = g;
+    }
+  }
+}
+
+extern "C" int jspsr_gate_mlp_forward(const float* avg, const float* mx, const float* w1, const float* w2, int B, int C, int Ch,
+                                      float* s, float* hid, jspsr_stream_t stream) {
+  if (!avg || !mx || !w1 || !w2 || !s || !hid || B <= 0 || C <= 0 || Ch <= 0 || Ch > 4096)
+    return fail(JSPSR_EINVAL, "gate_mlp_forward: bad arguments");
+  hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3(B), dim3(GM_T), Ch * sizeof(float), static_cast<hipStream_t>(stream), avg, mx, w1, w2,
+                     C, Ch, s, hid);
+  return check_launch("gate_mlp_forward");
+}
+
+extern "C" size_t jspsr_gate_mlp_backward_workspace_bytes(int B, int C, int Ch) {
+  if (B <= 0 || C <= 0 || Ch <= 0) return 0;
+  return ((size_t)B * C + (size_t)B * 2 * Ch) * sizeof(float);
+}
+
+extern "C" int jspsr_gate_mlp_backward(const float* ds, const float* s, const float* hid, const float* avg, const float* mx,
+                                       const float* w1, const float* w2, int B, int C, int Ch, float* davg, float* dmax,
+                                       float* dw1, float* dw2, void* workspace, jspsr_stream_t stream) {
+  if (!ds || !s || !hid || !avg || !mx || !w1 || !w2 || !davg || !dmax || !dw1 || !dw2 || !workspace || B <= 0 || C <= 0 ||
+      Ch <= 0 || (size_t)(C + 2 * Ch) * sizeof(float) > 64 * 1024)
+    return fail(JSPSR_EINVAL, "gate_mlp_backward: bad arguments");
+  float* dzs = static_cast<float*>(workspace);
+  float* dhs = dzs + (size_t)B * C;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3(B), dim3(GM_T), (C + 2 * Ch) * sizeof(float), st, ds, s, hid, w1, w2, C, Ch, davg, dmax,
+                     dzs, dhs);
+  if (int e = check_launch("gate_mlp_backward")) return e;
+  const long long n2 = 2LL * C * Ch;
+  const int blocks = (int)((n2 + GM_T - 1) / GM_T > 2048 ? 2048 : (n2 + GM_T - 1) / GM_T);
+  hipLaunchKernelGGL(gate_mlp_wgrad_kernel, dim3(blocks), dim3(GM_T), 0, st, dzs, dhs, hid, avg, mx, B, C, Ch, dw1, dw2);
+  return check_launch("gate_mlp_wgrad");
+}

@@ -343,3 +343,29 @@ def nchw_to_nhwc(x, dtype, c_pad):
     _lib.check(lib.jspsr_nchw_to_nhwc(BF16 if dtype == torch.bfloat16 else F32, x.data_ptr(), out.data_ptr(),
                                       B, C, H, W, c_pad, _stream()), "jspsr_nchw_to_nhwc")
     return out
+
+
+def gate_mlp_forward(avg, mx, w1, w2):
+    """s = sigmoid(W2 relu(W1 avg) + W2 relu(W1 mx)) on (B, C) vectors; w1 (Ch, C), w2 (C, Ch) fp32.  Returns (s, hid)."""
+    B, C = avg.shape
+    Ch = w1.shape[0]
+    s = torch.empty((B, C), dtype=torch.float32, device=avg.device)
+    hid = torch.empty((B, 2, Ch), dtype=torch.float32, device=avg.device)
+    lib = _lib.load()
+    _lib.check(lib.jspsr_gate_mlp_forward(avg.data_ptr(), mx.data_ptr(), w1.data_ptr(), w2.data_ptr(), B, C, Ch, s.data_ptr(),
+                                          hid.data_ptr(), _stream()), "jspsr_gate_mlp_forward")
+    return s, hid
+
+
+def gate_mlp_backward(ds, s, hid, avg, mx, w1, w2):
+    """Gradients of the gate MLP: (davg, dmax, dw1, dw2)."""
+    B, C = avg.shape
+    Ch = w1.shape[0]
+    davg, dmax = torch.empty_like(avg), torch.empty_like(avg)
+    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+    lib = _lib.load()
+    ws = torch.empty(lib.jspsr_gate_mlp_backward_workspace_bytes(B, C, Ch) // 4, dtype=torch.float32, device=avg.device)
+    _lib.check(lib.jspsr_gate_mlp_backward(ds.data_ptr(), s.data_ptr(), hid.data_ptr(), avg.data_ptr(), mx.data_ptr(), w1.data_ptr(),
+                                           w2.data_ptr(), B, C, Ch, davg.data_ptr(), dmax.data_ptr(), dw1.data_ptr(), dw2.data_ptr(),
+                                           ws.data_ptr(), _stream()), "jspsr_gate_mlp_backward")
+    return davg, dmax, dw1, dw2

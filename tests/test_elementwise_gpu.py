@@ -139,3 +139,24 @@ def test_boundary_conversion_nchw_to_nhwc(dtype, B, C, H, W):
     assert y.shape == ref.shape and torch.equal(y, ref)
     with pytest.raises(Exception):
         K.nchw_to_nhwc(x, dtype, C if C % e else C + 1)          # c_pad must be a whole number of 16-byte chunks
+
+
+@pytest.mark.parametrize("B,C", [(8, 1536), (2, 256), (3, 64), (1, 1024)])
+def test_gate_mlp_kernels_against_torch_autograd(B, C):
+    """jspsr_gate_mlp_forward / _backward (resnet_cbam.py:41-53 on the pooled vectors) == the same MLP written with torch
+    ops and differentiated by autograd, in fp64."""
+    from jspsr_amd import kernels as K
+    g = torch.Generator().manual_seed(B * 7 + C)
+    Ch = C // 16
+    avg, mx = torch.randn(B, C, generator=g), torch.randn(B, C, generator=g).abs() + 0.5
+    w1, w2 = torch.randn(Ch, C, generator=g) / C ** 0.5, torch.randn(C, Ch, generator=g) / Ch ** 0.5
+    ds = torch.randn(B, C, generator=g)
+    s, hid = K.gate_mlp_forward(avg.cuda(), mx.cuda(), w1.cuda(), w2.cuda())
+    a, m, u1, u2 = (t.double().requires_grad_() for t in (avg, mx, w1, w2))
+    h = lambda v: F.linear(F.relu(F.linear(v, u1)), u2)
+    ref = torch.sigmoid(h(a) + h(m))
+    assert _rel(s.cpu(), ref.detach()) < 2e-6
+    gr = torch.autograd.grad(ref, (a, m, u1, u2), ds.double())
+    out = K.gate_mlp_backward(ds.cuda(), s, hid, avg.cuda(), mx.cuda(), w1.cuda(), w2.cuda())
+    for o, r in zip(out, gr):
+        assert _rel(o.cpu(), r) < 5e-6
