@@ -166,6 +166,7 @@ class Model(HotPathModule):
         nb, nf2 = len(order), self.conv0.conv[0].out_channels
         bufs, fused, joined = [], [], []
         defer_skip = all(getattr(self, f"layer{s}_dem")[0].fused for s in (2, 3, 4))
+        deposit_ok = os.environ.get("JSPSR_GRAD_DEPOSIT", "1") != "0" and torch.is_grad_enabled()
         for s in range(1, 5):
             planes = nf2 * 2 ** (s - 1)
             if s > 1:
@@ -198,6 +199,14 @@ class Model(HotPathModule):
                         kw = {}
                         if k == 0 and from_fused and defer_skip:
                             kw["grad_extra"] = bufs[-1][0]      # the decoder's gradient of fused[s-1] is parked there
+                        elif k == 0 and s > 1 and defer_skip and br != "dem" and getattr(u, "fused", False) and deposit_ok:
+                            # this branch's previous-stage output feeds the stage join AND this unit: the unit adds its
+                            # gradient of it into the parked gradient of the join (its slice), in place, and the dem
+                            # branch's first block (which runs later in the backward pass) hands the sum on -- instead of
+                            # autograd adding two full tensors per branch and stage
+                            holder, w_prev = bufs[-1][0], planes // 2
+                            kw["grad_extra"] = (holder, i * w_prev, w_prev)
+                            holder.expected_deposits += 1
                         if k == len(units) - 1:
                             kw["dest"] = (buf, lead + i * planes)
                         src = u(src, **kw)

@@ -273,12 +273,20 @@ def head_rows():
 def merge_heads(w_weight, b_weight, w_offset, b_offset):
     """(9,C,1,1)/(9,) affinity head + (16,C,1,1)/(16,) offset head -> (32,C,1,1)/(32,) tap-major merged head
     (differentiable: the gradients of the merged rows flow back to the two reference-named parameters)."""
-    zw, zb = w_weight.new_zeros((1,) + tuple(w_weight.shape[1:])), b_weight.new_zeros(1)
-    pick_w = {"w": w_weight, "o": w_offset, "z": zw}
-    pick_b = {"w": b_weight, "o": b_offset, "z": zb}
-    rows = head_rows()
-    return (torch.cat([pick_w[kind][i:i + 1] for kind, i in rows], 0),
-            torch.cat([pick_b[kind][i:i + 1] for kind, i in rows], 0))
+    # one gather from [affinity rows | offset rows | a zero row] (a row-by-row concatenation costs ~100 tiny kernels
+    # per step, forward and backward, for the same 32 rows)
+    nw, no = w_weight.shape[0], w_offset.shape[0]
+    base = {"w": 0, "o": nw, "z": nw + no}
+    key = (nw, no, w_weight.device)
+    idx = _head_index.get(key)
+    if idx is None:
+        idx = _head_index[key] = torch.tensor([base[kind] + i for kind, i in head_rows()], device=w_weight.device)
+    stack_w = torch.cat((w_weight, w_offset, w_weight.new_zeros((1,) + tuple(w_weight.shape[1:]))), 0)
+    stack_b = torch.cat((b_weight, b_offset, b_weight.new_zeros(1)), 0)
+    return stack_w.index_select(0, idx), stack_b.index_select(0, idx)
+
+
+_head_index = {}
 
 
 def split_head(head):
@@ -517,9 +525,22 @@ class SliceBuffer:
     def __init__(self, B, H, W, C, dtype, device):
         self.buf = torch.empty((B, H, W, C), dtype=dtype, device=device)
         self.deferred = None     # see join(defer=...)
+        self.deferred_event = None      # recorded where the parked gradient was produced
+        self.deposit_events = []        # recorded by every res_unit that added its input gradient into the parked one
+        self.expected_deposits = 0      # how many such units the forward pass set up
 
     def take_deferred(self):
+        """The parked gradient, for the unit that adds it in its data-gradient epilogue.  Units that DEPOSIT into it
+        (res_unit(grad_extra=(self, first_channel, channels)), possibly on other streams) must all have run."""
         g, self.deferred = self.deferred, None
+        if g is not None:
+            if len(self.deposit_events) != self.expected_deposits:
+                raise RuntimeError(f"SliceBuffer: {len(self.deposit_events)} of {self.expected_deposits} deposits into the parked "
+                                   "gradient had run when it was taken (autograd order changed?)")
+            cur = torch.cuda.current_stream()
+            for ev in self.deposit_events:
+                cur.wait_event(ev)
+            self.deposit_events = []
         return g
 
     def slice(self, lo, n, shape=None):
@@ -562,6 +583,8 @@ class _Join(torch.autograd.Function):
             outs.append(g.narrow(3, off, w) if i < keep else None)
             if i == keep:
                 ctx.holder.deferred = g.narrow(3, off, sum(ctx.widths[keep:]))
+                ctx.holder.deferred_event = torch.cuda.current_stream().record_event()
+                ctx.holder.deposit_events = []
             off += w
         return (None, None, None) + tuple(outs)
 
@@ -809,7 +832,24 @@ class _ResUnit(torch.autograd.Function):
         dWd = dgd = dbd = None
         side = dres                      # what reaches x along the shortcut
         # gradient of x parked by its other consumer (SliceBuffer.join(defer=...)): rides along as an addend too
-        extra = ctx.grad_extra.take_deferred() if ctx.grad_extra is not None else None
+        deposit = None
+        if isinstance(ctx.grad_extra, tuple):
+            # (holder, first channel, channels): `x` is one part of a joined tensor whose OTHER consumer parked its
+            # gradient in `holder`; a third consumer of the joined tensor takes the parked gradient later (take_deferred).
+            # This unit adds its own gradient of `x` into the parked slice in place -- out = addend's slice of the final
+            # data-gradient launch -- and reports no gradient: autograd's full-tensor add where the two gradients of `x`
+            # would meet does not happen (2 x 3 passes over full-resolution tensors per step)
+            holder, off, n = ctx.grad_extra
+            if holder.deferred is not None and has_d and need_x:
+                cur = torch.cuda.current_stream()
+                cur.wait_event(holder.deferred_event)
+                deposit = holder.deferred.narrow(3, off, n)
+                deposit.record_stream(cur)
+                if tuple(deposit.shape) != tuple(x.shape):
+                    raise RuntimeError(f"res_unit: parked gradient slice {tuple(deposit.shape)} does not match the input {tuple(x.shape)}")
+            elif holder.deferred is not None:
+                holder.expected_deposits -= 1          # this unit cannot deposit (no projection shortcut): ordinary gradient
+        extra = ctx.grad_extra.take_deferred() if (ctx.grad_extra is not None and not isinstance(ctx.grad_extra, tuple)) else deposit
         if extra is not None:
             extra = K.nhwc(extra)
             if tuple(extra.shape) != tuple(x.shape):
@@ -824,7 +864,10 @@ class _ResUnit(torch.autograd.Function):
             dWd = _wgrad_async(pd, dzd, x, O, Cin, 1, 1, stride, 0)
             side = K.conv2d_dgrad(dzd, _packed(pd, wd, 1, O, cdt), (H, W), stride, 0, addend=extra) if need_x else None
         dx = None
-        if need_x:
+        if need_x and deposit is not None:
+            K.conv2d_dgrad(dz1, _packed(p1, w1, 1, O, cdt), (H, W), stride, 1, addend=K.nhwc(side), out=deposit)
+            ctx.grad_extra[0].deposit_events.append(torch.cuda.current_stream().record_event())
+        elif need_x:
             dx = K.conv2d_dgrad(dz1, _packed(p1, w1, 1, O, cdt), (H, W), stride, 1, addend=K.nhwc(side))
         return (dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None, None, None, None, None)
 

@@ -1,11 +1,12 @@
-"""Lab: which aten operators (torch's own small kernels) still run inside the benchmark step, by call count."""
-import os, sys, torch
+"""Lab: which aten operators (torch's own small kernels) still run inside the benchmark step, and from where."""
+import collections, os, sys, traceback, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from jspsr_amd.JSPSR import Model
 from jspsr_amd.ddp import GradReducer
 from jspsr_amd.losses import MultiLoss
 from jspsr_amd.optim import FlatAdamW
+from torch.utils._python_dispatch import TorchDispatchMode
 dev = torch.device("cuda", 0)
 model = Model(in_channels=bench.IN_CHANNELS, num_feature=32).to(dev).train()
 model.compute_dtype = torch.bfloat16
@@ -16,11 +17,23 @@ def step():
     red.zero_grad(); crit(model(*inputs), gt)["Total"].backward(); red.finish(); opt.step()
 for _ in range(3): step()
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    step(); torch.cuda.synchronize()
-rows = [(e.key, e.count, e.device_time_total) for e in prof.key_averages(group_by_stack_n=4) if e.key.startswith("aten::") and e.device_time_total > 0]
-rows.sort(key=lambda r: -r[1])
-for e in sorted(prof.key_averages(group_by_stack_n=4), key=lambda e: -e.count)[:40]:
-    if e.key.startswith("aten::") and e.device_time_total > 0:
-        print(f"{e.key:28s} n={e.count:4d} dev={e.device_time_total:9.1f}us  {' <- '.join(s.split('/')[-1] for s in e.stack[:3])}")
+counts = collections.Counter()
+SKIP = ("aten.view", "aten.detach", "aten._unsafe_view", "aten.alias", "aten.t.", "aten.slice", "aten.select", "aten.permute",
+        "aten.reshape", "aten.expand", "aten.as_strided", "aten.unsqueeze", "aten.squeeze", "aten.transpose", "aten.empty", "aten.record_stream",
+        "aten.is_", "aten.sym_", "aten.split", "aten.unbind", "aten.narrow", "aten._local_scalar", "aten.lift_fresh", "aten.flatten")
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            where = "?"
+            for fr in reversed(traceback.extract_stack()[:-1]):
+                if "jspsr_amd" in fr.filename or fr.filename.endswith("bench.py"):
+                    where = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+                    break
+            counts[(name, where)] += 1
+        return func(*args, **(kwargs or {}))
+with Log():
+    step()
+torch.cuda.synchronize()
+for (name, where), n in counts.most_common(45):
+    print(f"{n:5d}  {name:34s} {where}")
