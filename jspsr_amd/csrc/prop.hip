@@ -21,6 +21,15 @@
 #include <initializer_list>
 #include <type_traits>
 
+namespace jspsr {   // prop_dma.hip: the persistent LDS-DMA form of the same kernels (16-byte rows, aligned operands)
+int prop_dma_max_rows();
+bool prop_dma_ok(int B, int H, int W, int oc, std::initializer_list<const void*> ptrs);
+int prop_dma_forward(const float* dem, const float* weight, const float* offset, int oc, const float* wk, const float* b0,
+                     float scale, float* out, int B, int H, int W, hipStream_t s);
+int prop_dma_backward(const float* gout, const float* dem, const float* weight, const float* offset, int oc, const float* wk,
+                      float* gweight, float* goffset, float* partial, int B, int H, int W, hipStream_t s);
+}  // namespace jspsr
+
 namespace {
 
 // PX consecutive pixels of one plane per lane: PX*4-byte loads when the row pitch and the
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ dem,
     const float* __restrict__ weight, const float* __restrict__ offset,
     const float* __restrict__ wk, float* __restrict__ gweight, float* __restrict__ goffset,
-    float* __restrict__ partial, Geom g) {
+    float* __restrict__ partial, Geom g) {      // partial: 16-byte header (row count) + one row per workgroup
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float lds[LH * LW];
   __shared__ float red[NT / 64][NRED];
@@ -248,8 +257,9 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) v += red[w][threadIdx.x];
-    partial[(size_t)blockIdx.x * NRED + threadIdx.x] = v;
+    partial[4 + (size_t)blockIdx.x * NRED + threadIdx.x] = v;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(partial)[0] = (int)gridDim.x;
 }
 
 // Tile shape.  Defaults are what measured best on MI355X; JSPSR_PROP_TH x JSPSR_PROP_TW select one of the
@@ -347,10 +357,12 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
   if (int e = make_geom(B, H, W, g)) return e;
   for (const void* p : {(const void*)dem, (const void*)weight, (const void*)offset, (const void*)out})
     if (!jspsr::aligned4(p)) return jspsr::fail(JSPSR_EALIGN, "prop_forward: pointer not 4-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (jspsr::prop_dma_ok(B, H, W, offset_channels, {dem, weight, offset, out}))
+    return jspsr::prop_dma_forward(dem, weight, offset, offset_channels, wk, b0, scale, out, B, H, W, s);
   const int px = g.tw == 64 ? prop_px() : 1;
   const bool vec = can_vec(W, px, {dem, weight, offset, out});
   g.dem_vec4 = can_vec(W, 4, {dem});
-  hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(g.nblk), block(NT);
   by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
     hipLaunchKernelGGL((prop_fwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
@@ -363,7 +375,11 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
 extern "C" size_t jspsr_prop_backward_workspace_bytes(int B, int H, int W) {
   Geom g;
   if (make_geom(B, H, W, g)) return 0;
-  return ((size_t)g.nblk * NRED * sizeof(float) + 15) & ~(size_t)15;
+  const size_t rows = (size_t)g.nblk > (size_t)jspsr::prop_dma_max_rows() ? (size_t)g.nblk : (size_t)jspsr::prop_dma_max_rows();
+#ifdef K1D_STAMPS
+  return 16 + 4096 * NRED * sizeof(float) + (1 << 20);                  // lab build: cycle stamps behind the rows
+#endif
+  return 16 + ((rows * NRED * sizeof(float) + 15) & ~(size_t)15);      // header (row count) + rows, whichever path runs
 }
 
 extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, const float* weight,
@@ -381,20 +397,25 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
                         (const void*)grad_weight, (const void*)grad_offset})
     if (!jspsr::aligned4(p)) return jspsr::fail(JSPSR_EALIGN, "prop_backward: pointer not 4-byte aligned");
   if (!jspsr::aligned16(workspace)) return jspsr::fail(JSPSR_EALIGN, "prop_backward: workspace not 16-byte aligned");
-  const int px = g.tw == 64 ? prop_px() : 1;
-  const bool vec = can_vec(W, px, {grad_out, dem, weight, offset, grad_weight, grad_offset});
-  g.dem_vec4 = can_vec(W, 4, {dem});
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
-  dim3 grid(g.nblk), block(NT);
-  by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
-    hipLaunchKernelGGL((prop_bwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
-                                        decltype(THc)::value, decltype(TWc)::value>),
-                       grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g);
-  });
-  if (int e = jspsr::check_launch("prop_backward")) return e;
+  if (jspsr::prop_dma_ok(B, H, W, offset_channels, {grad_out, dem, weight, offset, grad_weight, grad_offset})) {
+    if (int e = jspsr::prop_dma_backward(grad_out, dem, weight, offset, offset_channels, wk, grad_weight, grad_offset, partial, B, H, W, s))
+      return e;
+  } else {
+    const int px = g.tw == 64 ? prop_px() : 1;
+    const bool vec = can_vec(W, px, {grad_out, dem, weight, offset, grad_weight, grad_offset});
+    g.dem_vec4 = can_vec(W, 4, {dem});
+    dim3 grid(g.nblk), block(NT);
+    by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
+      hipLaunchKernelGGL((prop_bwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
+                                          decltype(THc)::value, decltype(TWc)::value>),
+                         grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g);
+    });
+    if (int e = jspsr::check_launch("prop_backward")) return e;
+  }
   if (!grad_wk) return JSPSR_OK;   // partial rows only: the caller folds them later (jspsr_prop_backward_fold_f32)
-  hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, g.nblk, grad_wk, grad_b0);
+  hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, -1, grad_wk, grad_b0);
   return jspsr::check_launch("prop_backward_finalize");
 }
 
@@ -404,6 +425,6 @@ extern "C" int jspsr_prop_backward_fold_f32(const void* workspace, int B, int H,
   Geom g;
   if (int e = make_geom(B, H, W, g)) return e;
   hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const float*>(workspace), g.nblk, grad_wk, grad_b0);
+                     static_cast<const float*>(workspace), -1, grad_wk, grad_b0);
   return jspsr::check_launch("prop_backward_fold");
 }

@@ -130,11 +130,16 @@ __device__ __forceinline__ void tile_coords(const Geom& g, int& b, int& ty0, int
 }
 
 // One workgroup per parameter gradient (9 tap weights + bias): 256 lanes stride over the partial
-// rows in fp64, then a fixed-order tree -> bit-reproducible run to run.
+// rows in fp64, then a fixed-order tree -> bit-reproducible run to run.  nblk < 0: the planar entry's workspace, whose
+// first 16 bytes hold the row count the streaming kernel wrote (its grid depends on the path taken), rows behind it.
 __global__ __launch_bounds__(256) void prop_bwd_finalize(const float* __restrict__ partial,
                                                         int nblk, float* __restrict__ gwk,
                                                         float* __restrict__ gb0) {
   __shared__ double red[4];
+  if (nblk < 0) {
+    nblk = *reinterpret_cast<const int*>(partial);
+    partial += 4;
+  }
   const int col = blockIdx.x;
   double s = 0.0;
   for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partial[(size_t)i * NRED + col];

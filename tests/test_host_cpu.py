@@ -60,7 +60,7 @@ def test_cabi_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.jspsr_prop_forward_f32(None, None, None, 18, None, None, 1.0, None, 1, 8, 8, None) == -1
     assert b"null" in lib.jspsr_last_error()
-    assert lib.jspsr_prop_backward_workspace_bytes(8, 512, 512) == 4096 * 10 * 4  # 64x8 tiles
+    assert lib.jspsr_prop_backward_workspace_bytes(8, 512, 512) == 16 + 4096 * 10 * 4  # row-count header + 64x8 tiles
     assert lib.jspsr_prop_backward_workspace_bytes(0, 512, 512) == 0
 
 
