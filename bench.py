@@ -153,17 +153,34 @@ def time_k1(model, inputs, iters=20):
     pmc = os.path.join(ROOT, "profiles", "k1_pmc.json")
     if os.path.exists(pmc):
         traffic = json.load(open(pmc))
+    in_model = {
+        "kernel": head["kernel"], "dtype": head["dtype"],
+        "note": "what the benchmarked step launches for spn.py:99-118 (K1h: operands straight from the merged head's NHWC "
+                "output); algorithmic = (25 operand elements (+ 25 gradients) in the storage dtype + fp32 dem + fp32 out / "
+                "grad_out) per pixel, moved = the 32-channel layout's bytes",
+        "forward": {"us_per_launch": head["fwd_us"], "achieved": head["fwd_algorithmic_GBs"],
+                    "frac": round(head["fwd_algorithmic_GBs"] / HBM_PEAK_GBS, 4),
+                    "moved_GBs": head["fwd_moved_GBs"], "moved_frac": round(head["fwd_moved_GBs"] / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get(f"head_{head['dtype']}_fwd_bytes_per_launch") if traffic else None},
+        "backward": {"us_per_launch": head["bwd_us"], "achieved": head["bwd_algorithmic_GBs"],
+                     "frac": round(head["bwd_algorithmic_GBs"] / HBM_PEAK_GBS, 4),
+                     "moved_GBs": head["bwd_moved_GBs"], "moved_frac": round(head["bwd_moved_GBs"] / HBM_PEAK_GBS, 4),
+                     "traffic": traffic.get(f"head_{head['dtype']}_bwd_bytes_per_launch") if traffic else None},
+    }
+    kname = lambda d: (traffic or {}).get(f"{d}_kernel", "prop_dma_kernel<16, 4, %s, true, %s>" % (("false", "true") if d == "fwd" else ("true", "false")))
     return {
-        "bound": "hbm", "kernel": "prop_bwd_kernel<16>", "achieved": round(bw_b, 1),
+        "bound": "hbm", "kernel": kname("bwd"), "achieved": round(bw_b, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bw_b / HBM_PEAK_GBS, 4),
         "traffic": traffic.get("bwd_bytes_per_launch") if traffic else None,
         "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2),
         "us_per_call_with_fold": round(res["bwd_call"] * 1e6, 2),
-        "forward": {"kernel": "prop_fwd_kernel<16>", "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
+        "forward": {"kernel": kname("fwd"), "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get("fwd_bytes_per_launch") if traffic else None,
                     "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2)},
+        "kernel_in_model": in_model["kernel"], "in_model": in_model,
         "head_entry": head,
-        "note": "algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / "
+        "note": "the PostProcessor.forward boundary (planar fp32 operands, the public operator: spn.py:99-118) on the persistent "
+                "LDS-DMA kernels of csrc/prop_dma.hip; in_model = the same step as the models launch it; algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / "
                 "mean launch duration (events on the launch stream, back-to-back launches of that kernel alone; "
                 "us_per_call_with_fold adds the 10-workgroup fold launch of the backward C-ABI call); traffic = PMC "
                 "FETCH_SIZE+WRITE_SIZE per launch from profiles/k1_pmc.json (separate rocprofv3 --pmc passes)",

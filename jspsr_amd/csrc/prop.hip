@@ -1,12 +1,15 @@
-// K1 -- fused spatial propagation for gfx950 (MI355X), forward and backward.
+// K1 -- fused spatial propagation for gfx950 (MI355X), forward and backward: the C-ABI entry points, and the GENERAL
+// kernels (any width, any alignment).  Rows of 16-byte-aligned operands with W % 4 == 0 -- every shape the models and
+// the benchmark produce -- take the persistent LDS-DMA kernels of prop_dma.hip instead (same arithmetic).
 //
 // Restates, in one pass over HBM, PostProcessor.forward of the reference
 // (models/components/spn.py:99-118): zero-sum affinities, 3x3 deformable bilinear gather of a
 // one-channel DEM (torchvision deform_conv2d semantics), learnable 3x3
-// tap weights + bias, residual add.  HBM-bound: 116 B/pixel forward, 224 B/pixel backward
-// (108 / 208 with the 16-channel offset layout that drops the all-zero centre pair).
+// tap weights + bias, residual add.  HBM-bound; algorithmic bytes per pixel: 108 forward / 208 backward
+// with the 16-channel offset layout the models use (the all-zero centre pair is not stored), 116 / 224 with
+// torchvision's 18 channels.
 //
-// Data movement
+// Data movement of the general kernels
 //   * a workgroup (256 threads = 4 waves) owns a TH x TW pixel tile of one image (default 8 x 64; JSPSR_PROP_TH /
 //     JSPSR_PROP_TW); a lane owns PX consecutive pixels of one row per pass (default 1: a wave instruction is one
 //     256-byte row segment of one operand plane; 2 / 4 = 8- / 16-byte loads, measured slower: DESIGN.md);

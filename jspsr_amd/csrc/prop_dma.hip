@@ -18,7 +18,7 @@
 //   * compute: one pixel per lane out of LDS (conflict-free ds_read_b32, plane = immediate offset);
 //   * backward: the 25|27 gradient planes go back IN PLACE over the operands in LDS and leave as 16-byte
 //     non-temporal stores, again four plane segments per wave instruction;
-//   * parameter gradients: fp64 per lane across the whole run, one reduction per workgroup (no atomics).
+//   * parameter gradients: per lane across the whole run, one fp64 reduction per workgroup (no atomics).
 #include "prop_tile.h"
 
 #include <cstdlib>
@@ -57,6 +57,7 @@ struct DmaCfg {
   static constexpr int DPW = (PIECES + NW - 1) / NW;   // DEM pieces per wave
   static constexpr int DEMB = PIECES * 1024;
   static constexpr int SMEM = 2 * DEMB + 2 * NW * OPB;
+  static_assert(LH * DLW + DLW + 2 <= DEMB / 4, "zero pad behind the staged DEM tile (gather_taps)");
 };
 
 template <int OC>
@@ -81,56 +82,75 @@ __device__ __forceinline__ void dma_piece(unsigned lds_dst, const void* src) {
 #define K1D_STAMP(i) do { } while (0)
 #endif
 
+#ifndef K1D_NTS
+#define K1D_NTS 1          // gradient planes leave as non-temporal stores
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 
-// The nine taps' corner fetches at once: 36 LDS reads issued back to back at clamped indices (zeroed by select when the
-// sample lies outside tile + halo), then ONE wave-level test for the rare lanes that need the bounds-checked global
-// fallback (a tap more than HALO pixels outside the tile but still near the raster).  Same values as corners_fast().
-template <int LH, int LW>
-__device__ __forceinline__ void gather9(const float* __restrict__ lds, const float* __restrict__ img, int H, int W, int ly0, int lx0,
-                                        const float (&py)[9], const float (&px)[9], Corners (&c)[9]) {
-  unsigned fbmask = 0;
+// NT_ taps' corner fetches at once.  Same values as corners_fast() (prop_tile.h), fewer instructions per tap:
+//   * floor + convert = v_cvt_flr_i32_f32, the fractional part = v_fract_f32 (differs from p - floor(p) only for p a
+//     hair below an integer: 1 - 2^-24 instead of the rounded 1.0);
+//   * the four LDS reads are issued unconditionally; a sample outside tile + halo reads the ZERO pad behind the staged
+//     tile (ZPAD: the DEM pieces' out-of-range lanes land zeros there every tile), so no select zeroes anything;
+//   * every rarer case -- a tap beyond the halo but near the raster (bounds-checked global reads), a tap outside the
+//     raster, NaN / inf coordinates (the tap contributes 0) -- sits behind ONE wave-level test per call.
+template <int LH, int LW, int NT_, int ZPAD>
+__device__ __forceinline__ void gather_taps(const float* __restrict__ lds, const float* __restrict__ img, int H, int W, int ly0, int lx0,
+                                            const float (&py)[NT_], const float (&px)[NT_], Corners (&c)[NT_]) {
+  unsigned out = 0;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const float fy = floorf(py[k]), fx = floorf(px[k]);
-    c[k].ly = py[k] - fy;
-    c[k].lx = px[k] - fx;
+  for (int k = 0; k < NT_; ++k) {
     // fmaxf / fminf return the non-NaN operand: NaN and +-inf coordinates become huge finite ones (out of every range)
-    const int y0 = (int)fminf(fmaxf(fy, -1.0e9f), 1.0e9f), x0 = (int)fminf(fmaxf(fx, -1.0e9f), 1.0e9f);
-    const int ry = y0 - ly0, rx = x0 - lx0;
-    const bool inl = (unsigned)ry < (unsigned)(LH - 1) && (unsigned)rx < (unsigned)(LW - 1);
-    const bool near = (py[k] > -2.f) && (py[k] < (float)(H + 1)) && (px[k] > -2.f) && (px[k] < (float)(W + 1));   // false for NaN
-    const float* p = lds + (inl ? ry * LW + rx : 0);
-    const float t00 = p[0], t01 = p[1], t10 = p[LW], t11 = p[LW + 1];
-    c[k].v00 = inl ? t00 : 0.f;
-    c[k].v01 = inl ? t01 : 0.f;
-    c[k].v10 = inl ? t10 : 0.f;
-    c[k].v11 = inl ? t11 : 0.f;
-    if (near && !inl) fbmask |= 1u << k;
-    if (!near && !inl) c[k].ly = c[k].lx = 0.f;   // keep inf/nan coordinates out of the arithmetic: the tap contributes 0
+    const float cy = fminf(fmaxf(py[k], -1.0e9f), 1.0e9f), cx = fminf(fmaxf(px[k], -1.0e9f), 1.0e9f);
+    int y0, x0;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(y0) : "v"(cy));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(x0) : "v"(cx));
+    c[k].ly = __builtin_amdgcn_fractf(cy);
+    c[k].lx = __builtin_amdgcn_fractf(cx);
+    const unsigned ry = (unsigned)y0 - (unsigned)ly0, rx = (unsigned)x0 - (unsigned)lx0;
+    const bool inl = ry < (unsigned)(LH - 1) && rx < (unsigned)(LW - 1);
+    const float* p = lds + (inl ? ry * LW + rx : (unsigned)ZPAD);
+    c[k].v00 = p[0];
+    c[k].v01 = p[1];
+    c[k].v10 = p[LW];
+    c[k].v11 = p[LW + 1];
+    if (!inl) out |= 1u << k;
   }
-  if (__builtin_amdgcn_ballot_w64(fbmask != 0) != 0) {
+  if (__builtin_amdgcn_ballot_w64(out != 0) != 0) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      if ((fbmask >> k) & 1u) {
-        const int y0 = (int)floorf(py[k]), x0 = (int)floorf(px[k]);      // near the raster: finite and small
-        const bool y0ok = (unsigned)y0 < (unsigned)H, y1ok = (unsigned)(y0 + 1) < (unsigned)H;
-        const bool x0ok = (unsigned)x0 < (unsigned)W, x1ok = (unsigned)(x0 + 1) < (unsigned)W;
-        const float* q = img + (ptrdiff_t)y0 * W + x0;
-        if (y0ok && x0ok) c[k].v00 = q[0];
-        if (y0ok && x1ok) c[k].v01 = q[1];
-        if (y1ok && x0ok) c[k].v10 = q[W];
-        if (y1ok && x1ok) c[k].v11 = q[W + 1];
+    for (int k = 0; k < NT_; ++k) {
+      if ((out >> k) & 1u) {
+        const bool near = (py[k] > -2.f) && (py[k] < (float)(H + 1)) && (px[k] > -2.f) && (px[k] < (float)(W + 1));   // false for NaN
+        if (near) {
+          const int y0 = (int)floorf(py[k]), x0 = (int)floorf(px[k]);
+          const bool y0ok = (unsigned)y0 < (unsigned)H, y1ok = (unsigned)(y0 + 1) < (unsigned)H;
+          const bool x0ok = (unsigned)x0 < (unsigned)W, x1ok = (unsigned)(x0 + 1) < (unsigned)W;
+          const float* q = img + (ptrdiff_t)y0 * W + x0;
+          if (y0ok && x0ok) c[k].v00 = q[0];
+          if (y0ok && x1ok) c[k].v01 = q[1];
+          if (y1ok && x0ok) c[k].v10 = q[W];
+          if (y1ok && x1ok) c[k].v11 = q[W + 1];
+        } else {
+          c[k].ly = c[k].lx = 0.f;   // keep inf/nan coordinates out of the arithmetic: the tap contributes 0
+        }
       }
     }
   }
 }
 
-template <int OC, int NW, bool BWD, bool NTL>
-__global__ __launch_bounds__(NW * 64) void prop_dma_kernel(const DmaArgs A) {
+// One tile t of a workgroup's run, operand / DEM buffers t % 2.  Two roles:
+//   mover:   wait for its pieces of tile t | barrier | request tile t+1 into the other buffers
+//   compute: barrier | tile t, one pixel per lane, results in place | backward: the row's 25|27 gradient planes out
+// SPLIT = false: NW waves, each plays both roles for its row (8 waves per CU: LDS holds two 7 KB buffers per row).
+// SPLIT = true:  NW compute waves (0 .. NW-1) + NW mover waves (NW .. 2 NW-1); mover NW + w loads what compute wave w
+//                consumes, so a compute wave never pays the issue time of an LDS-DMA instruction (200-400 cycles each
+//                while the memory pipeline is backed up), and the tile's bytes are requested as soon as the barrier falls.
+template <int OC, int NW, bool BWD, bool NTL, bool SPLIT>
+__global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop_dma_kernel(const DmaArgs A) {
   using C = DmaCfg<NW>;
   constexpr int LH = C::LH;
   constexpr int NPL = 9 + OC + (BWD ? 1 : 0);      // operand planes staged per row
@@ -143,7 +163,9 @@ __global__ __launch_bounds__(NW * 64) void prop_dma_kernel(const DmaArgs A) {
   __shared__ double red[NW][NRED];
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool mover = !SPLIT || wave_all >= NW, computes = !SPLIT || wave_all < NW;
+  const int wave = wave_all >= NW ? wave_all - NW : wave_all;      // the tile row this wave serves
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
   const int H = A.H, W = A.W;
   const size_t P = (size_t)H * W;
@@ -161,9 +183,13 @@ __global__ __launch_bounds__(NW * 64) void prop_dma_kernel(const DmaArgs A) {
     ty = r / A.tiles_x;
     tx = r - ty * A.tiles_x;
   }
+#ifdef K1D_STAMPS
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long first_ = last_;
+#endif
 
-  // ---- tile-invariant lane plans ------------------------------------------------------------------------------------
-  // operand / gradient piece i: plane 4 i + lane / 16, 16-byte chunk lane % 16 of the row segment
+  // ---- mover: tile-invariant lane plans ------------------------------------------------------------------------------
+  // operand piece i: plane 4 i + lane / 16, 16-byte chunk lane % 16 of the row segment
   const int lq = lane >> 4, lc = lane & 15;
   unsigned loff[NPIECE];
 #pragma unroll
@@ -179,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void prop_dma_kernel(const DmaArgs A) {
     const int q = (wave + j * NW) * 64 + lane;
     const int rr = q / (DLW / 4), cc = (q - rr * (DLW / 4)) * 4;
     doff[j] = (rr * W + cc) * 4;
-    dcx[j] = q < C::CHUNKS ? cc : (1 << 30);      // beyond the tile: never inside the raster
+    dcx[j] = q < C::CHUNKS ? cc : (1 << 30);      // beyond the tile: never inside the raster (the DMA lands zeros: ZPAD)
   }
 
   auto issue_tile = [&](int ib, int ity, int itx, int buf) __attribute__((always_inline)) {
@@ -216,133 +242,140 @@ __global__ __launch_bounds__(NW * 64) void prop_dma_kernel(const DmaArgs A) {
     }
   };
 
+  // ---- compute: constants and running sums -----------------------------------------------------------------------------
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = A.wk[k];
   const float bias = BWD ? 0.f : A.b0[0];
-  double dsum[NRED];
+  // parameter-gradient partial sums: fp32 per LANE over the run's tiles (one value per tile: a few dozen additions
+  // of like-sized terms), fp64 from there on (across lanes, waves, workgroups -- where the cancellation is)
+  float dsum[NRED];
 #pragma unroll
-  for (int i = 0; i < NRED; ++i) dsum[i] = 0.0;
+  for (int i = 0; i < NRED; ++i) dsum[i] = 0.f;
 
-#ifdef K1D_STAMPS
-  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-  const unsigned long long first_ = last_;
-#endif
-  issue_tile(b, ty, tx, 0);
-  bool counted = false;      // the previous tile of this wave issued its NST stores after the pieces waited for here
+  if (mover) issue_tile(b, ty, tx, 0);
+  bool counted = false;      // (not SPLIT) this wave issued NST stores behind the pieces it waits for next
   int buf = 0;
 #pragma unroll 1
   for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
-    // this wave's pieces of tile t have landed (all but the NST younger stores of tile t-1); then everybody's
     K1D_STAMP(5);
-    if (counted) wait_vm<NST>(); else wait_vm<0>();
+    if (mover) {
+      // this wave's pieces of tile t have landed (all but its NST younger stores of tile t-1)
+      if (!SPLIT && counted) wait_vm<NST>(); else wait_vm<0>();
+    }
     K1D_STAMP(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous tile's LDS traffic is done (a raw barrier waits for nothing)
     __builtin_amdgcn_s_barrier();
     K1D_STAMP(1);
     // tile t+1 into the other buffers: every wave is past its reads of them (tile t-1) -- it is past the barrier
     int nb = b, nty = ty, ntx = tx + 1;
     if (ntx == A.tiles_x) { ntx = 0; if (++nty == A.tiles_y) { nty = 0; ++nb; } }
-    if (t + 1 < t_end) issue_tile(nb, nty, ntx, buf ^ 1);
+    if (mover && t + 1 < t_end) issue_tile(nb, nty, ntx, buf ^ 1);
     K1D_STAMP(2);
 
     const int y0 = ty * NW, x0 = tx * DW;
     const int y = y0 + wave, x = x0 + lane;
     counted = y < H;
-    if (y < H) {       // wave-uniform
-      const float* dl = reinterpret_cast<const float*>(smem + buf * C::DEMB);
+    if (computes && y < H) {       // wave-uniform
       float* ob = reinterpret_cast<float*>(smem + 2 * C::DEMB + (buf * NW + wave) * OPB);
-      const float* img = A.dem + (size_t)b * P;
-      const int ly0 = y0 - HALO, lx0 = x0 - HALO;
-      const size_t pix = (size_t)y * W + x0;
       if (x < W) {
-        float a[9], oy[9], ox[9];
+        const float* dl = reinterpret_cast<const float*>(smem + buf * C::DEMB);
+        const float* img = A.dem + (size_t)b * P;
+        const int ly0 = y0 - HALO, lx0 = x0 - HALO;
+        float a[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) a[k] = ob[k * 64 + lane];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          if (OC == 18 || k != 4) {
-            oy[k] = ob[(9 + dch<OC>(k, 0)) * 64 + lane];
-            ox[k] = ob[(9 + dch<OC>(k, 1)) * 64 + lane];
-          } else {
-            oy[k] = ox[k] = 0.f;
-          }
-        }
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) s += a[k];
         const float mean = s / 9.f;
-        float py[9], px[9];
+        const float gj = BWD ? ob[(9 + OC) * 64 + lane] : 0.f;
+        float gm[9];
+        float acc = bias, gsum = 0.f;
+        // TG taps at a time (3 bounds the live registers to 128 per lane: four waves per SIMD in the SPLIT form)
+        constexpr int TG = SPLIT ? 3 : 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          py[k] = (float)(y - 1 + k / 3) + oy[k];
-          px[k] = (float)(x - 1 + k % 3) + ox[k];
-        }
-        Corners cr[9];
+        for (int g3 = 0; g3 < 9 / TG; ++g3) {
+          float py[TG], px[TG];
+#pragma unroll
+          for (int j = 0; j < TG; ++j) {
+            const int k = TG * g3 + j;
+            float oy = 0.f, ox = 0.f;
+            if (OC == 18 || k != 4) {
+              oy = ob[(9 + dch<OC>(k, 0)) * 64 + lane];
+              ox = ob[(9 + dch<OC>(k, 1)) * 64 + lane];
+            }
+            py[j] = (float)(y - 1 + k / 3) + oy;
+            px[j] = (float)(x - 1 + k % 3) + ox;
+          }
+          Corners cr[TG];
 #ifdef K1D_NOCOMPUTE
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { cr[k].v00 = py[k]; cr[k].v01 = px[k]; cr[k].v10 = cr[k].v11 = 0.f; cr[k].ly = cr[k].lx = 0.5f; }
+          for (int j = 0; j < TG; ++j) { cr[j].v00 = py[j]; cr[j].v01 = px[j]; cr[j].v10 = cr[j].v11 = 0.f; cr[j].ly = cr[j].lx = 0.5f; }
 #else
-        gather9<LH, DLW>(dl, img, H, W, ly0, lx0, py, px, cr);
+          gather_taps<LH, DLW, TG, LH * DLW>(dl, img, H, W, ly0, lx0, py, px, cr);
 #endif
-        if (!BWD) {
-          float acc = bias;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const Corners& c = cr[k];
+          for (int j = 0; j < TG; ++j) {
+            const int k = TG * g3 + j;
+            const Corners& c = cr[j];
             const float hy = 1.f - c.ly, hx = 1.f - c.lx;
             const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
-            acc += wreg[k] * (a[k] - mean) * S;
-          }
-          A.out[(size_t)b * P + pix + lane] = acc + A.scale * dl[(y - ly0) * DLW + (x - lx0)];
-        } else {
-          const float gj = ob[(9 + OC) * 64 + lane];
-          float gm[9], gy[9], gx[9];
-          float gsum = 0.f;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const Corners& c = cr[k];
-            const float hy = 1.f - c.ly, hx = 1.f - c.lx;
-            const float S = hy * hx * c.v00 + hy * c.lx * c.v01 + c.ly * hx * c.v10 + c.ly * c.lx * c.v11;
-            const float dSdy = hx * (c.v10 - c.v00) + c.lx * (c.v11 - c.v01);
-            const float dSdx = hy * (c.v01 - c.v00) + c.ly * (c.v11 - c.v10);
             const float m = a[k] - mean;
-            const float coef = gj * wreg[k] * m;
-            gy[k] = coef * dSdy;
-            gx[k] = coef * dSdx;
-            const float gmk = gj * wreg[k] * S;
-            gm[k] = gmk;
-            gsum += gmk;
-            dsum[k] += (double)(gj * m * S);
-          }
-          gsum /= 9.f;
-          // results over the operands, in place (every operand of this pixel is in registers by now)
-#pragma unroll
-          for (int k = 0; k < 9; ++k) ob[k * 64 + lane] = gm[k] - gsum;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            if (OC == 18 || k != 4) {
-              ob[(9 + dch<OC>(k, 0)) * 64 + lane] = gy[k];
-              ob[(9 + dch<OC>(k, 1)) * 64 + lane] = gx[k];
+            if (!BWD) {
+              acc += wreg[k] * m * S;
+            } else {
+              const float dSdy = hx * (c.v10 - c.v00) + c.lx * (c.v11 - c.v01);
+              const float dSdx = hy * (c.v01 - c.v00) + c.ly * (c.v11 - c.v10);
+              const float coef = gj * wreg[k] * m;
+              if (OC == 18 || k != 4) {      // in place: this tap's offsets are in registers, nobody else reads them
+                ob[(9 + dch<OC>(k, 0)) * 64 + lane] = coef * dSdy;
+                ob[(9 + dch<OC>(k, 1)) * 64 + lane] = coef * dSdx;
+              }
+              const float gmk = gj * wreg[k] * S;
+              gm[k] = gmk;
+              gsum += gmk;
+              dsum[k] += gj * m * S;
             }
           }
-          dsum[9] += (double)gj;
+        }
+        if (!BWD) {
+          A.out[(size_t)b * P + (size_t)y * W + x] = acc + A.scale * dl[(y - ly0) * DLW + (x - lx0)];
+        } else {
+          gsum /= 9.f;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) ob[k * 64 + lane] = gm[k] - gsum;
+          dsum[9] += gj;
         }
       }
       K1D_STAMP(3);
       if (BWD) {
-        // the row's gradient planes, four 256-byte plane segments per wave instruction (same wave wrote them: LDS
-        // operations of one wave complete in order)
+        // the row's finished gradient planes: four 256-byte plane segments per wave instruction, non-temporal (this wave
+        // wrote them: the LDS operations of one wave complete in order)
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));      // recomputed per tile: hoisted out of the loop the seven lane offsets cost seven registers
+        const int sq = lane_ >> 4, sc = lane_ & 15;
+        const char* obc = reinterpret_cast<const char*>(ob);
+        const size_t pix = (size_t)y * W + x0;
         char* gwb = reinterpret_cast<char*>(A.gweight + (size_t)b * 9 * P + pix);
         char* gob = reinterpret_cast<char*>(A.goffset + (size_t)b * OC * P + pix);
-        const bool colok = x0 + lc * 4 < W;
+        const bool colok = x0 + sc * 4 < W;
+        const unsigned plane_b = (unsigned)(P * 4);
+        // two batches (4 + 3 pieces): all seven lifted at once cost 28 registers the compute part has no room for
 #pragma unroll
-        for (int i = 0; i < NOPIECE; ++i) {
-          const int p = 4 * i + lq;
-          if (colok && p < NOUTPL) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ob) + i * 1024 + lane * 16);
-            char* dst = (p < 9 ? gwb : gob) + loff[i];
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+        for (int i0 = 0; i0 < NOPIECE; i0 += 4) {
+          f32x4 v[4];
+#pragma unroll
+          for (int i = i0; i < i0 + 4 && i < NOPIECE; ++i) v[i - i0] = *reinterpret_cast<const f32x4*>(obc + i * 1024 + lane_ * 16);
+#pragma unroll
+          for (int i = i0; i < i0 + 4 && i < NOPIECE; ++i) {
+            const int p = 4 * i + sq;
+            if (colok && p < NOUTPL) {
+              f32x4* dst = reinterpret_cast<f32x4*>((p < 9 ? gwb : gob) + ((unsigned)(p < 9 ? p : p - 9) * plane_b + sc * 16));
+              if (K1D_NTS) __builtin_nontemporal_store(v[i - i0], dst); else *dst = v[i - i0];
+            }
           }
+          asm volatile("" ::: "memory");
         }
       }
     }
@@ -351,20 +384,21 @@ __global__ __launch_bounds__(NW * 64) void prop_dma_kernel(const DmaArgs A) {
   }
 #ifdef K1D_STAMPS
   if (BWD && lane == 0) {
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(A.partial + 4 + 4096 * NRED) + ((size_t)blockIdx.x * NW + wave) * 8;
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(A.partial + 4 + 4096 * NRED) + ((size_t)blockIdx.x * 2 * NW + wave_all) * 8;
     for (int i = 0; i < 6; ++i) o[i] = stamp[i];
     o[6] = __builtin_amdgcn_s_memtime() - first_;
     o[7] = (unsigned long long)(t_end - t_begin);
   }
 #endif
-
   if (BWD) {
+    if (computes) {
 #pragma unroll
-    for (int i = 0; i < NRED; ++i) {
-      double v = dsum[i];
+      for (int i = 0; i < NRED; ++i) {
+        double v = (double)dsum[i];
 #pragma unroll
-      for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-      if (lane == 0) red[wave][i] = v;
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) red[wave][i] = v;
+      }
     }
     __syncthreads();
     if (threadIdx.x < NRED) {
@@ -397,16 +431,19 @@ namespace {
 
 struct Plan {
   int nw, grid;
-  bool ntl;
+  bool ntl, split;
 };
 
-Plan make_plan(int B, int H, int W, DmaArgs& A) {
-  static const int nw_env = env_int("JSPSR_PROP_NW", 8);
-  static const int ntl_env = env_int("JSPSR_PROP_NTL", 1);
+Plan make_plan(int B, int H, int W, bool bwd, DmaArgs& A) {
+  // defaults = what measured best on MI355X; the environment is for A/B measurements
+  static const int nw_env = env_int("JSPSR_PROP_NW", 4);
+  static const int ntl_env = env_int("JSPSR_PROP_NTL", -1);
+  static const int split_env = env_int("JSPSR_PROP_SPLIT", -1);
   static const int wgs_env = env_int("JSPSR_PROP_WGS", 0);     // workgroups per CU (0 = what the LDS admits)
   Plan p;
-  p.nw = nw_env == 4 ? 4 : 8;
-  p.ntl = ntl_env != 0;
+  p.nw = nw_env == 8 ? 8 : 4;
+  p.ntl = ntl_env < 0 ? true : ntl_env != 0;
+  p.split = split_env < 0 ? !bwd : split_env != 0;
   A.B = B; A.H = H; A.W = W;
   A.tiles_x = (W + DW - 1) / DW;
   A.tiles_y = (H + p.nw - 1) / p.nw;
@@ -419,16 +456,17 @@ Plan make_plan(int B, int H, int W, DmaArgs& A) {
   return p;
 }
 
+template <int OC, bool BWD, int NW, bool NTL>
+void launch3(const Plan& p, const DmaArgs& A, hipStream_t s) {
+  const dim3 grid(p.grid);
+  if (p.split) hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, true>), grid, dim3(2 * NW * 64), 0, s, A);
+  else         hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, false>), grid, dim3(NW * 64), 0, s, A);
+}
+
 template <int OC, bool BWD>
 void launch(const Plan& p, const DmaArgs& A, hipStream_t s) {
-  const dim3 grid(p.grid);
-  if (p.nw == 8) {
-    if (p.ntl) hipLaunchKernelGGL((prop_dma_kernel<OC, 8, BWD, true>), grid, dim3(512), 0, s, A);
-    else       hipLaunchKernelGGL((prop_dma_kernel<OC, 8, BWD, false>), grid, dim3(512), 0, s, A);
-  } else {
-    if (p.ntl) hipLaunchKernelGGL((prop_dma_kernel<OC, 4, BWD, true>), grid, dim3(256), 0, s, A);
-    else       hipLaunchKernelGGL((prop_dma_kernel<OC, 4, BWD, false>), grid, dim3(256), 0, s, A);
-  }
+  if (p.nw == 8) { if (p.ntl) launch3<OC, BWD, 8, true>(p, A, s); else launch3<OC, BWD, 8, false>(p, A, s); }
+  else           { if (p.ntl) launch3<OC, BWD, 4, true>(p, A, s); else launch3<OC, BWD, 4, false>(p, A, s); }
 }
 
 }  // namespace
@@ -453,7 +491,7 @@ int prop_dma_forward(const float* dem, const float* weight, const float* offset,
                      float scale, float* out, int B, int H, int W, hipStream_t s) {
   DmaArgs A{};
   A.dem = dem; A.weight = weight; A.offset = offset; A.wk = wk; A.b0 = b0; A.out = out; A.scale = scale;
-  const Plan p = make_plan(B, H, W, A);
+  const Plan p = make_plan(B, H, W, false, A);
   if (oc == 18) launch<18, false>(p, A, s); else launch<16, false>(p, A, s);
   return check_launch("prop_forward (dma)");
 }
@@ -463,7 +501,7 @@ int prop_dma_backward(const float* gout, const float* dem, const float* weight, 
   DmaArgs A{};
   A.dem = dem; A.weight = weight; A.offset = offset; A.gout = gout; A.wk = wk; A.gweight = gweight; A.goffset = goffset;
   A.partial = partial;
-  const Plan p = make_plan(B, H, W, A);
+  const Plan p = make_plan(B, H, W, true, A);
   if (oc == 18) launch<18, true>(p, A, s); else launch<16, true>(p, A, s);
   return check_launch("prop_backward (dma)");
 }

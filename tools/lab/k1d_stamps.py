@@ -25,12 +25,14 @@ raw = ws.cpu().numpy()
 import numpy as np
 rows = int(np.frombuffer(raw[:4].tobytes(), dtype=np.int32)[0])
 nw = int(os.environ.get("JSPSR_PROP_NW", "8"))
-st = np.frombuffer(raw[16 + 4096 * 40:16 + 4096 * 40 + rows * nw * 64].tobytes(), dtype=np.uint64).reshape(rows, nw, 8).astype(np.float64)
-tiles = st[..., 7]
-names = ["wait", "barrier", "issue", "compute", "store", "loop"]
-print(f"grid {rows} x {nw} waves, tiles per workgroup {tiles.mean():.1f}; cycles per tile per wave (mean / median / max over waves):")
-for i, n in enumerate(names):
-    v = st[..., i] / tiles
-    print(f"  {n:8s} {v.mean():8.0f} {np.median(v):8.0f} {v.max():8.0f}")
-tot = st[..., 6]
-print(f"  whole kernel per wave: mean {tot.mean():.0f} cycles, max {tot.max():.0f}  (s_memtime ticks)")
+st = np.frombuffer(raw[16 + 4096 * 40:16 + 4096 * 40 + rows * 2 * nw * 64].tobytes(), dtype=np.uint64).reshape(rows, 2, nw, 8).astype(np.float64)
+names = ["wait", "barrier", "lift+issue", "compute", "store", "loop"]
+for role, rn in ((0, "compute waves"), (1, "mover waves")):
+    r = st[:, role]
+    tiles = r[..., 7]
+    print(f"{rn}: grid {rows} x {nw}, tiles per workgroup {tiles.mean():.1f}; cycles per tile per wave (mean / median / max over waves):")
+    for i, n in enumerate(names):
+        v = r[..., i] / tiles
+        print(f"  {n:10s} {v.mean():8.0f} {np.median(v):8.0f} {v.max():8.0f}")
+    tot = r[..., 6]
+    print(f"  whole kernel per wave: mean {tot.mean():.0f} cycles, max {tot.max():.0f}  (s_memtime ticks)")
