@@ -136,7 +136,39 @@ def time_k1(model, inputs, iters=20):
         e1.record()
         e1.synchronize()
         res[name] = e0.elapsed_time(e1) / iters * 1e-3
+    # K1s: the general step of N-iteration chains (NLSPN, models/components/nlspn.py:177-233): raw affinities, gradients
+    # ADDED into the shared affinity / offset gradients, and the gradient with respect to the raster (LDS scatter + float
+    # atomics).  One step each way; algorithmic bytes = K1's + 4 B/px of grad_dem (+ the read of the accumulators).
+    from jspsr_amd import ops as O
+    ones9, zero1 = torch.ones(9, device=dev), torch.zeros(1, device=dev)
+    sws = O._step_workspace(B, H, W, dev)
+    gdem = torch.zeros_like(dem)
+
+    def sfwd(i):
+        O._step_forward(dem, sets[i % nset][0], sets[i % nset][1], ones9, zero1, 0.0, 0, out)
+
+    def sbwd(i):
+        O._step_backward(gout, dem, sets[i % nset][0], sets[i % nset][1], ones9, 0.0, 0, 1, gsets[i % nset][0], gsets[i % nset][1], gdem, sws)
+
+    for name, fn in (("sfwd", sfwd), ("sbwd", sbwd)):
+        for i in range(3):
+            fn(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        e1.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e-3
     px = B * H * W
+    steps_entry = {
+        "kernel": "prop_step_fwd_kernel / prop_step_bwd_kernel (K1s, csrc/prop_steps.hip)",
+        "fwd_us": round(res["sfwd"] * 1e6, 2), "bwd_us": round(res["sbwd"] * 1e6, 2),
+        "fwd_GBs": round(108.0 * px / res["sfwd"] / 1e9, 1), "bwd_GBs": round((208.0 + 100.0 + 8.0) * px / res["sbwd"] / 1e9, 1),
+        "note": "one propagation step of an N-iteration chain (NLSPN): forward 108 B/px; backward with accumulate = 1 reads "
+                "the 25 gradient planes it adds into (100 B/px) and adds grad_dem by float atomics (4 B/px each way) on top of K1's 208",
+    }
     head = {
         "kernel": f"prop_head_kernel<{'bf16' if es == 2 else 'f32'}>", "dtype": "bf16" if es == 2 else "f32",
         "fwd_us": round(res["hfwd"] * 1e6, 2), "bwd_us": round(res["hbwd"] * 1e6, 2),
@@ -179,6 +211,7 @@ def time_k1(model, inputs, iters=20):
                     "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2)},
         "kernel_in_model": in_model["kernel"], "in_model": in_model,
         "head_entry": head,
+        "steps_entry": steps_entry,
         "note": "the PostProcessor.forward boundary (planar fp32 operands, the public operator: spn.py:99-118) on the persistent "
                 "LDS-DMA kernels of csrc/prop_dma.hip; in_model = the same step as the models launch it; algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / "
                 "mean launch duration (events on the launch stream, back-to-back launches of that kernel alone; "
@@ -319,6 +352,39 @@ def fp32_legs(args, device, model, step):
                         "ms_per_step": round(t2 * 1e3, 3), "value": round(8 * 256 * 256 / t2 / 1e6, 4), "unit": "Mpixel/s"}}
 
 
+def inference_leg(model, device):
+    """BASELINE configs[4] as far as one GPU goes: the eval-mode forward of the SAME module on ONE rank's strip of a
+    4096 x 4096 scene split over 8 ranks (jspsr_amd/tiling.py: 512 interior rows + 128-row halos = what a rank computes),
+    BatchNorm folded into the conv epilogues (ops.conv_bn_infer).  Mpixel/s of interior pixels per GPU; the halo exchange
+    and the four gate all-reduces of the 8-rank run are not in it (tests/test_tiling_gpu.py runs those, over gloo)."""
+    from jspsr_amd import tiling
+    S, world, rank = 4096, 8, 3
+    s = tiling.plan_strips(S, world, 128)[rank]
+    rows = s.ty1 - s.ty0
+    g = torch.Generator(device=device).manual_seed(7)
+    tiles = [torch.rand(1, c, rows, S, device=device, generator=g) for c in (1, 3, 15)]
+    was_training = model.training
+    model.eval()
+    try:
+        run = lambda: tiling._run(model, tiles, [s], tiling._combine_batch)
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        t0, n = time.perf_counter(), 5
+        for _ in range(n):
+            _, reach = run()
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / n
+    finally:
+        model.train(was_training)
+    interior = (s.y1 - s.y0) * S
+    return {"workload": f"jspsr_r8_img_msk eval forward, one rank's window of a {S}x{S} scene over {world} ranks: rows "
+                        f"[{s.ty0},{s.ty1}) = {rows} x {S} px computed, {s.y1 - s.y0} x {S} interior",
+            "dtype": "bf16" if model.compute_dtype == torch.bfloat16 else "f32", "ms": round(t * 1e3, 2),
+            "value": round(interior / t / 1e6, 2), "computed_value": round(rows * S / t / 1e6, 2), "unit": "Mpixel/s forward per GPU",
+            "max_offset_px": round(max(reach), 2), "receptive_radius": tiling.RECEPTIVE_RADIUS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +397,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 legs (N = 1 only)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the whole-scene strip forward (N = 1 only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -414,8 +481,11 @@ def main():
     if rank == 0 and not args.no_roofline:
         roof = time_k1(model, inputs)
         roof["convs"] = time_convs(args.batch, model.compute_dtype)
+    infer = None
+    if rank == 0 and world == 1 and not args.no_inference:
+        infer = inference_leg(model, device)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:      # on rank 0 at every N: north_star wants the CPU figure "in the same run"
         cpu = cpu_baseline()
 
     if rank == 0:
@@ -443,10 +513,11 @@ def main():
             },
             "host": {"abi_calls_per_step": abi_calls, "enqueue_ms_per_step": round(host_ms, 2),
                      "note": "C-ABI entry points called per step (each launches 1-3 kernels) and the host time to enqueue "
-                             "them; enqueue_ms well under ms_per_step = the step is GPU-bound (no graph capture needed)"},
+                             "them with nothing to wait for; while it stays under ms_per_step the GPU, not the host, sets the step"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "fp32": fp32,
+            "inference": infer,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -29,6 +29,11 @@ typedef void* jspsr_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
 int jspsr_abi_version(void);
+/* Diagnostics: launches so far (this process) of the kernel family named `what` -- the names the error texts use:
+ * "conv64_resident" (K2r), "conv_patch", "conv_patch_16x16", "conv_igemm", "conv2d_wgrad_patch", "prop_forward (dma)",
+ * "prop_backward (dma)", "prop_forward", "prop_head_forward", ...  Lets a parity test assert that a shape really took
+ * the kernel it is meant to exercise.  -1 for a NULL name, 0 for a name never launched. */
+long long jspsr_launch_count(const char* what);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* jspsr_last_error(void);
 

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
+from . import ops
 from .blocks import HotPathModule
 from .spn import Generator, PostProcessor
 
@@ -33,6 +34,8 @@ class ResBlock(nn.Module):
 
 
 class EDSR(HotPathModule):
+    receptive_radius = None      # sharded inference (tiling.py): not certified for this network (check_reach=False only)
+
     def __init__(self, in_channels=3, out_channels=3, n_resblocks=16, n_features=64, scale=2, res_scale=0.1,
                  spn=False):
         super().__init__()
@@ -68,4 +71,6 @@ class EDSR(HotPathModule):
             tail = self.encoder[-1]
             h = E.conv2d(h, tail.weight, tail.bias, 1, 1) + self.res_scale * xs
             head = self.generator.head(self.generator.features(E.from_nchw(dem), h))
+            if E._offset_probe is not None:
+                E._offset_probe.append(ops.split_head(head)[1])
             return self.post_layer.from_head(dem.float(), head)

@@ -23,6 +23,10 @@ _AUX_KEYS = ("mask", "canopy", "coord")
 
 
 class Model(HotPathModule):
+    # pixels of input a prediction depends on beyond its own position, learned offsets aside (tiling.py certifies strips
+    # with it): stem 2 + encoder 4+8+16+32 + decoder 16+8+4 + conv0 1 + generator 5 + 3x3 sampler 1
+    receptive_radius = 97
+
     def __init__(self, in_channels: dict, out_channels: int = 1, num_feature: int = 32,
                  layers: tuple = (2, 2, 2, 2), res_scale: tuple = (1, 1, 1, 1), spn: bool = True,
                  spn_scale: int = 1):
@@ -166,7 +170,8 @@ class Model(HotPathModule):
         nb, nf2 = len(order), self.conv0.conv[0].out_channels
         bufs, fused, joined = [], [], []
         defer_skip = all(getattr(self, f"layer{s}_dem")[0].fused for s in (2, 3, 4))
-        deposit_ok = os.environ.get("JSPSR_GRAD_DEPOSIT", "1") != "0" and torch.is_grad_enabled()
+        # deposits (below) rely on the dem branch being the LAST of a stage to run in the backward pass: it is first here
+        deposit_ok = os.environ.get("JSPSR_GRAD_DEPOSIT", "1") != "0" and torch.is_grad_enabled() and order[0] == "dem"
         for s in range(1, 5):
             planes = nf2 * 2 ** (s - 1)
             if s > 1:

@@ -90,6 +90,12 @@ class PostProcess(nn.Module):
 
 
 class Model(HotPathModule):
+    # sharded inference (tiling.py): no certified receptive radius for this network (five stride-2 stages and four
+    # propagation steps applied to their own output) -> strips run only with check_reach=False; the steps still report
+    # their learned offsets, and their reaches add up
+    receptive_radius = None
+    offsets_chain = True
+
     def __init__(self, args, layers=(2, 2, 2, 2, 2)):
         super().__init__()
         self.args = args
@@ -152,6 +158,8 @@ class Model(HotPathModule):
         """One propagation step on the detached running estimate (LRRU.py:453-455 etc.)."""
         current = current.detach().float().contiguous()
         head = enc.head(E.from_nchw(current), context)
+        if E._offset_probe is not None:
+            E._offset_probe.append(ops.split_head(head)[1])
         return E.propagate_head(current, head, self.Post_process.w, self.Post_process.b, 1.0)
 
     def _keep_input(self, out, d_clear):

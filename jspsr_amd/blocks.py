@@ -28,6 +28,20 @@ class HotPathModule(nn.Module):
         else:
             super().zero_grad(set_to_none)
 
+    # The conv kernels read re-laid ("packed") copies of the weights, cached per Parameter and validated by torch's
+    # version counter (ops._packed).  Writes that bypass the counter (`p.data.mul_()`, `p.data.copy_()`: EMA, clipping,
+    # re-initialisation) would leave stale copies in use; the usual places such writes are followed by -- a train() /
+    # eval() switch, load_state_dict() -- therefore drop every cached copy.  Anything else that writes through `.data`
+    # must call ops.invalidate_packed_weights() itself.
+    def train(self, mode: bool = True):
+        ops.invalidate_packed_weights()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        ops.invalidate_packed_weights()
+        return out
+
 
 class ChannelGate(nn.Module):
     """Holds the shared bias-free 1x1 MLP of ChannelAttention (resnet_cbam.py:36-53)."""

@@ -789,7 +789,7 @@ int launch_patch(const void* in, const void* wgt, const float* bias, void* out, 
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTH), lds, s, static_cast<const T*>(in), static_cast<const T*>(wgt),
                      bias, static_cast<T*>(out), stats, g);
-  return check_launch("conv_patch");
+  return check_launch(BM == 256 ? (BN == 64 ? "conv_patch_16x16" : "conv_patch_16x16x128") : "conv_patch");
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN, int NBUF>

@@ -134,6 +134,10 @@ def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None
     IH, IW = in_hw
     if out is None:
         out = torch.empty((B, IH, IW, Cin), dtype=g.dtype, device=g.device)
+    else:
+        _chk_s(out, "conv2d_dgrad out")         # a dense NHWC tensor or a 16-byte-aligned channel slice of one
+        if tuple(out.shape[:3]) != (B, IH, IW) or out.shape[3] < out_coff + Cin or out.dtype != g.dtype:
+            raise ValueError(f"conv2d_dgrad: out {tuple(out.shape)} {out.dtype} cannot take a ({B},{IH},{IW},{Cin}) {g.dtype} result at channel {out_coff}")
     if addend is not None:
         _chk_s(addend, "conv2d_dgrad addend")
         if tuple(addend.shape) != (B, IH, IW, Cin) or addend.dtype != g.dtype:

@@ -528,14 +528,15 @@ class SliceBuffer:
         self.deferred_event = None      # recorded where the parked gradient was produced
         self.deposit_events = []        # recorded by every res_unit that added its input gradient into the parked one
         self.expected_deposits = 0      # how many such units the forward pass set up
+        self.pending_deposits = 0       # ... of which this backward pass still expects (re-armed by every _Join.backward)
 
     def take_deferred(self):
         """The parked gradient, for the unit that adds it in its data-gradient epilogue.  Units that DEPOSIT into it
         (res_unit(grad_extra=(self, first_channel, channels)), possibly on other streams) must all have run."""
         g, self.deferred = self.deferred, None
         if g is not None:
-            if len(self.deposit_events) != self.expected_deposits:
-                raise RuntimeError(f"SliceBuffer: {len(self.deposit_events)} of {self.expected_deposits} deposits into the parked "
+            if len(self.deposit_events) != self.pending_deposits:
+                raise RuntimeError(f"SliceBuffer: {len(self.deposit_events)} of {self.pending_deposits} deposits into the parked "
                                    "gradient had run when it was taken (autograd order changed?)")
             cur = torch.cuda.current_stream()
             for ev in self.deposit_events:
@@ -585,6 +586,7 @@ class _Join(torch.autograd.Function):
                 ctx.holder.deferred = g.narrow(3, off, sum(ctx.widths[keep:]))
                 ctx.holder.deferred_event = torch.cuda.current_stream().record_event()
                 ctx.holder.deposit_events = []
+                ctx.holder.pending_deposits = ctx.holder.expected_deposits     # per backward pass: a second backward over a retained graph starts afresh
             off += w
         return (None, None, None) + tuple(outs)
 
@@ -844,11 +846,17 @@ class _ResUnit(torch.autograd.Function):
                 cur = torch.cuda.current_stream()
                 cur.wait_event(holder.deferred_event)
                 deposit = holder.deferred.narrow(3, off, n)
-                deposit.record_stream(cur)
                 if tuple(deposit.shape) != tuple(x.shape):
                     raise RuntimeError(f"res_unit: parked gradient slice {tuple(deposit.shape)} does not match the input {tuple(x.shape)}")
+                if deposit.dtype != x.dtype or not (deposit.is_contiguous() or K.is_slice(deposit)):
+                    # autograd handed the join a gradient that is not a dense NHWC tensor of the compute dtype: the kernel
+                    # would write it with the wrong pitch -- fall back to the ordinary gradient of x (autograd adds)
+                    holder.pending_deposits -= 1
+                    deposit = None
+                else:
+                    deposit.record_stream(cur)
             elif holder.deferred is not None:
-                holder.expected_deposits -= 1          # this unit cannot deposit (no projection shortcut): ordinary gradient
+                holder.pending_deposits -= 1           # this unit cannot deposit (no projection shortcut): ordinary gradient
         extra = ctx.grad_extra.take_deferred() if (ctx.grad_extra is not None and not isinstance(ctx.grad_extra, tuple)) else deposit
         if extra is not None:
             extra = K.nhwc(extra)

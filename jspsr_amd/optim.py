@@ -31,8 +31,11 @@ class FlatAdamW:
         self.param_groups = [{"lr": float(lr), "initial_lr": float(lr), "ranges": []}]
         by_lr = {}
         off = 0
+        self._slices = {}                            # id(parameter) -> (offset, numel) in the flat buffers
+        self._over = over
         for p in reversed(reducer.params):          # same order as the gradient buffer
             n = p.numel()
+            self._slices[id(p)] = (off, n)
             self.flat_p[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + n].view_as(p)
             if id(p) in over:
@@ -82,8 +85,37 @@ class FlatAdamW:
 
     # -- checkpointing: the reference saves optimizer.state_dict() with every best model (main.py:246-252) and
     #    restores it on resume (utils/utils.py:394) -------------------------------------------------------------------
-    def state_dict(self):
-        """Flat moments + step count + per-group learning rates; tensors are clones (safe to torch.save)."""
+    def _torch_order(self):
+        """The parameters in the order torch.optim.AdamW numbers them when built as the reference builds it
+        (utils/common_config.py:241-258): model.parameters() order, the `diff_lr` parameters moved to a second group."""
+        plain = [p for p in self.reducer.params if id(p) not in self._over]
+        groups = [plain]
+        for g in self.param_groups[1:]:
+            groups.append([p for p in self.reducer.params if self._over.get(id(p)) == g["initial_lr"] or self._over.get(id(p)) == g["lr"]])
+        return groups
+
+    def state_dict(self, layout="flat"):
+        """layout="flat" (default): flat moments + step count + per-group learning rates; tensors are clones (safe to
+        torch.save).  layout="torch": the dict torch.optim.AdamW.state_dict() would hold for the same parameters
+        (per-parameter `exp_avg` / `exp_avg_sq` / `step`, `param_groups` with `params` indices) -- what the reference
+        writes into its checkpoints (main.py:246-252) and can resume from (utils/utils.py:394)."""
+        if layout == "torch":
+            state, groups, idx = {}, [], 0
+            for g, plist in zip(self.param_groups, self._torch_order()):
+                ids = []
+                for p in plist:
+                    off, n = self._slices[id(p)]
+                    state[idx] = {"step": torch.tensor(float(self.steps)),
+                                  "exp_avg": self.exp_avg[off:off + n].detach().clone().view_as(p),
+                                  "exp_avg_sq": self.exp_avg_sq[off:off + n].detach().clone().view_as(p)}
+                    ids.append(idx)
+                    idx += 1
+                groups.append({"lr": g["lr"], "initial_lr": g["initial_lr"], "betas": tuple(self.betas), "eps": self.eps,
+                               "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+                               "capturable": False, "differentiable": False, "fused": None, "params": ids})
+            return {"state": state if self.steps else {}, "param_groups": groups}
+        if layout != "flat":
+            raise ValueError("FlatAdamW.state_dict: layout must be 'flat' or 'torch'")
         return {
             "state": {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
                       "step": int(self.steps)},
@@ -94,7 +126,16 @@ class FlatAdamW:
         }
 
     def load_state_dict(self, sd):
-        """In place: the parameters keep aliasing `flat_p`, the gradients keep aliasing the reducer's buffer."""
+        """In place: the parameters keep aliasing `flat_p`, the gradients keep aliasing the reducer's buffer.  Accepts
+        this class's flat layout and torch.optim.AdamW's (a checkpoint the reference wrote: per-parameter state scattered
+        into the flat buffers in parameter order)."""
+        if not isinstance(sd, dict) or "param_groups" not in sd or "state" not in sd:
+            raise ValueError("FlatAdamW.load_state_dict: not an optimizer state dict (no 'state' / 'param_groups')")
+        if "numel" not in sd:
+            if not all("params" in g for g in sd["param_groups"]):
+                raise ValueError("FlatAdamW.load_state_dict: unknown optimizer checkpoint format (neither FlatAdamW's flat "
+                                 "layout nor torch.optim.AdamW's)")
+            return self._load_torch(sd)
         if int(sd["numel"]) != self.flat_p.numel() or len(sd["param_groups"]) != len(self.param_groups):
             raise ValueError("FlatAdamW.load_state_dict: checkpoint was written for a different parameter layout")
         for g, sg in zip(self.param_groups, sd["param_groups"]):
@@ -106,6 +147,38 @@ class FlatAdamW:
         self.exp_avg.copy_(sd["state"]["exp_avg"])
         self.exp_avg_sq.copy_(sd["state"]["exp_avg_sq"])
         self.steps = int(sd["state"]["step"])
+
+
+    def _load_torch(self, sd):
+        order = self._torch_order()
+        if len(sd["param_groups"]) != len(order) or any(len(g["params"]) != len(pl) for g, pl in zip(sd["param_groups"], order)):
+            raise ValueError("FlatAdamW.load_state_dict: the torch AdamW checkpoint groups its parameters differently "
+                             f"({[len(g['params']) for g in sd['param_groups']]} vs {[len(pl) for pl in order]}): build the "
+                             "optimizer with the same lr_overrides (diff_lr) as the run that wrote it")
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for g, sg, plist in zip(self.param_groups, sd["param_groups"], order):
+            g["lr"], g["initial_lr"] = float(sg["lr"]), float(sg.get("initial_lr", sg["lr"]))
+            for pid, p in zip(sg["params"], plist):
+                st = sd["state"].get(pid)
+                if st is None:
+                    continue                          # torch keeps no state for a parameter that never had a gradient
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"FlatAdamW.load_state_dict: parameter {pid} has shape {tuple(st['exp_avg'].shape)} in the "
+                                     f"checkpoint, {tuple(p.shape)} here")
+                off, n = self._slices[id(p)]
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdamW.load_state_dict: parameters at different step counts {sorted(steps)} (one fused step "
+                             "count is kept)")
+        first = sd["param_groups"][0]
+        if first.get("amsgrad") or first.get("maximize"):
+            raise ValueError("FlatAdamW.load_state_dict: amsgrad / maximize checkpoints are not supported")
+        self.betas, self.eps, self.weight_decay = tuple(first["betas"]), float(first["eps"]), float(first["weight_decay"])
+        self.steps = steps.pop() if steps else 0
 
 
 class WarmupStepLR:

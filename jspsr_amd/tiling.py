@@ -84,7 +84,8 @@ class _GateSync:
         return self.combine(torch.cat(sums), cnt, torch.cat(maxs))
 
 
-RECEPTIVE_RADIUS = 97   # stem 2 + encoder 4+8+16+32 + decoder 16+8+4 + conv0 1 + generator 5 + 3x3 sampler 1
+RECEPTIVE_RADIUS = 97   # JSPSR: stem 2 + encoder 4+8+16+32 + decoder 16+8+4 + conv0 1 + generator 5 + 3x3 sampler 1;
+                        # the certified figure is a per-model attribute (`Model.receptive_radius`), this is JSPSR's
 
 
 class HaloTooSmall(RuntimeError):
@@ -116,6 +117,10 @@ def _run(model, tiles, windows, combine, check_reach=True):
     the offsets are unbounded reals, so exactness is checked per scene, not assumed)."""
     if model.training:
         raise RuntimeError("sharded inference needs model.eval(): BatchNorm batch statistics would couple the strips")
+    radius = getattr(model, "receptive_radius", None)
+    if check_reach and radius is None:
+        raise RuntimeError(f"{type(model).__name__} has no certified receptive radius (Model.receptive_radius): the strip result "
+                           "cannot be certified equal to the monolithic forward; pass check_reach=False to run it uncertified")
     prev, prev_probe = E._gate_sync, E._offset_probe
     E._gate_sync = _GateSync(windows, combine)
     E._offset_probe = probe = []
@@ -124,18 +129,23 @@ def _run(model, tiles, windows, combine, check_reach=True):
             out = model(*tiles)
     finally:
         E._gate_sync, E._offset_probe = prev, prev_probe
+    if check_reach and not probe:
+        raise RuntimeError(f"{type(model).__name__} reported no learned offsets during the sharded forward: the halo check "
+                           "would pass vacuously (every propagation step must append to engine._offset_probe)")
+    chained = bool(getattr(model, "offsets_chain", False))   # steps applied to their own output: the reaches add up
     reach = []
     for b, s in enumerate(windows):
         r = 0.0
         for off in probe:                                   # NHWC (B,h,w,16) learned offsets of a propagation step
             rows = off[b, s.y0 - s.ty0:s.y1 - s.ty0]
             if rows.numel():
-                r = max(r, rows.abs().max().item())
+                m = rows.abs().max().item()
+                r = r + m if chained else max(r, m)
         reach.append(r)
         margin = min(s.margins())
-        if check_reach and r + RECEPTIVE_RADIUS > margin:
+        if check_reach and r + radius > margin:
             raise HaloTooSmall(f"strip rows [{s.y0},{s.y1}): learned offsets reach {r:.1f} px; with the receptive radius of "
-                               f"{RECEPTIVE_RADIUS} px that needs {r + RECEPTIVE_RADIUS:.0f} halo rows, the window holds {margin}")
+                               f"{radius} px that needs {r + radius:.0f} halo rows, the window holds {margin}")
     return out, reach
 
 

@@ -129,23 +129,119 @@ def gradient_noise_floor(forward, sd, inputs, probe, g_ref, n_trials=2, n_roundi
     return {k: tuple(v) for k, v in floors.items()}
 
 
-SMOOTH = ("postprocessor.", "post_layer.", "Post_process.", ".conv_weight.")
+# ---- where a gradient may legitimately jump: a census of the network's kinks ------------------------------------------
+def kink_census(forward, sd, inputs, forward_dev=None, pred_ref=None, factor=10.0, patience=4):
+    """Every point of the oracle's graph where the gradient is discontinuous in the activations, with a count of the
+    elements that sit close enough to the discontinuity for an fp32 implementation to land on the other side:
+      * ReLU (every F.relu of the oracle): pre-activation z, at risk if |z| < factor x dev;
+      * the channel gate's global max-pool (resnet_cbam.py:44: the gradient goes to the arg-max pixel): at risk if the
+        two largest values of a channel are closer than factor x dev;
+      * the bilinear sampler (spn.py:105): a learned tap (not the constant centre one) at risk if its coordinate is
+        within factor x dev of an integer, where d/d(offset) jumps.
+    dev = max |fp32 evaluation - fp64 evaluation| of THAT tensor in the oracle (the deviation an fp32 implementation
+    shows at that point), scaled up by (forward deviation of the implementation under test / the fp32 oracle's own) when
+    that ratio exceeds 1.  For every at-risk kink the set of parameters UPSTREAM of it (the ones whose gradient passes
+    through it) is found structurally (autograd.grad of the kink tensor, allow_unused).  -> list of dicts
+    (index, kind, shape, dev, n_risk, upstream)."""
+    real_F, real_ca, real_st = R.F, R.channel_attention, R.sample_taps
+
+    def run(dtype, grad):
+        rec = []
+
+        class Rec:
+            def __getattr__(self, name):
+                return getattr(real_F, name)
+
+            def relu(self, x, *a, **k):
+                rec.append(("relu", x))
+                return real_F.relu(x, *a, **k)
+
+        def ca(c, x, p_):
+            rec.append(("gate-max " + p_, x))
+            return real_ca(c, x, p_)
+
+        def st(dem, offset):
+            rec.append(("sampler", offset))
+            return real_st(dem, offset)
+
+        cast = lambda v: v.detach().to(dtype) if v.is_floating_point() else v.clone()
+        sd_ = {k: cast(v) for k, v in sd.items()}
+        params = {k: v.requires_grad_() for k, v in sd_.items() if grad and v.is_floating_point() and "running" not in k}
+        sd_.update(params)
+        try:
+            R.F, R.channel_attention, R.sample_taps = Rec(), ca, st
+            with torch.enable_grad() if grad else torch.no_grad():
+                pred = forward(sd_, [cast(t) for t in inputs])
+        finally:
+            R.F, R.channel_attention, R.sample_taps = real_F, real_ca, real_st
+        return pred, rec, params
+
+    p64, r64, params = run(torch.float64, True)
+    p32, r32, _ = run(torch.float32, False)
+    assert len(r64) == len(r32) and all(a[0] == b[0] for a, b in zip(r64, r32))
+    scale = 1.0
+    if forward_dev is not None and pred_ref is not None:
+        own = (p32.double() - pred_ref).abs().max().item()
+        scale = max(1.0, forward_dev / max(own, 1e-30))
+    names, plist = list(params), list(params.values())
+    out = []
+    for i, ((kind, z), (_, z32)) in enumerate(zip(r64, r32)):
+        zd = z.detach()
+        dev = scale * (z32.double() - zd).abs().max().item()
+        if kind == "relu":
+            n = int((zd.abs() < factor * dev).sum())
+        elif kind.startswith("gate-max"):
+            top = zd.flatten(2).topk(2, dim=2).values
+            n = int(((top[..., 0] - top[..., 1]) < factor * dev).sum())
+        else:
+            B, C, H, W = zd.shape
+            ys = torch.arange(H, dtype=zd.dtype).view(1, 1, H, 1)
+            xs = torch.arange(W, dtype=zd.dtype).view(1, 1, 1, W)
+            pos = zd.clone()
+            pos[:, 0::2] += ys
+            pos[:, 1::2] += xs
+            d = (pos - pos.round()).abs()
+            d[:, 8:10] = 1.0                                   # the centre tap's offset is the constant 0
+            n = int((d < factor * dev).sum())
+        out.append({"index": i, "kind": kind, "shape": tuple(zd.shape), "dev": dev, "n_risk": n, "upstream": None})
+    # who is upstream of an at-risk kink: one backward pass per kink, from the output end of the network (the late kinks
+    # have nearly every parameter upstream); stop once `patience` further kinks add no parameter that was not already
+    # covered -- the listing per parameter is then a subset of its at-risk kinks, the tolerance tiers are exact
+    covered, idle = set(), 0
+    for kk, (kind, z) in reversed(list(zip(out, r64))):
+        if kk["n_risk"] == 0 or not z.requires_grad or idle >= patience:
+            continue
+        gs = torch.autograd.grad(z.sum(), plist, retain_graph=True, allow_unused=True)
+        kk["upstream"] = {k for k, g in zip(names, gs) if g is not None}
+        idle = 0 if kk["upstream"] - covered else idle + 1
+        covered |= kk["upstream"]
+    return out
 
 
-def gradient_tolerances(floor, factor=2.0):
-    """Per-parameter tolerance from the measured floors.  A ReLU-mask flip is a discrete event: a given draw either
-    hits one inside a sub-network or it does not, and the handful of oracle draws cannot visit every sub-network (seen
-    on the GPU: one flip in LRRU's last affinity encoder, whose own floor read 4e-6 because none of the draws flipped
-    there, while every other encoder's floor read 5e-3).  What the draws DO measure is what a flip costs in this
-    network: the median floor over all parameters.  Parameters behind at least one ReLU get
-    factor x max(own floor, that median); parameters whose gradient never crosses a ReLU or a sampler kink (tap
-    weights, affinity head: `SMOOTH`) keep factor x their own floor."""
+def gradient_tolerances(floor, census, factor=2.0):
+    """Per-parameter tolerance from the measured floors and the kink census.  A parameter with NO at-risk kink between it
+    and the output must meet factor x its OWN measured floor (1e-6 .. 1e-5: nothing discrete can happen to its
+    gradient).  A parameter upstream of at least one at-risk kink may see a flip -- a discrete event: a given draw of
+    the noise floor either hits one inside a sub-network or does not, and the handful of oracle draws cannot visit every
+    sub-network; what the draws DO measure is what a flip costs in this network, the median floor over all
+    parameters -- and gets factor x max(own floor, that median).  -> ({name: tolerance}, {name: [at-risk kink indices
+    downstream of it]})."""
     med = float(np.median([v[1] for v in floor.values()]))
-    tol = {}
-    for k, v in floor.items():
-        smooth = any(s in k for s in SMOOTH)
-        tol[k] = factor * (v[1] if smooth else max(v[1], med)) + 1e-5
-    return tol
+    risky = {}
+    for kk in census:
+        if kk["n_risk"] > 0 and kk["upstream"]:
+            for name in kk["upstream"]:
+                risky.setdefault(name, []).append(kk["index"])
+    tol = {k: factor * (max(v[1], med) if k in risky else v[1]) + 1e-5 for k, v in floor.items()}
+    return tol, risky
+
+
+def describe_census(census):
+    risk = [k for k in census if k["n_risk"] > 0]
+    head = f"{len(census)} kinks ({sum(k['kind'] == 'relu' for k in census)} ReLU), {len(risk)} with elements at risk"
+    rows = [f"  #{k['index']:3d} {k['kind']:28s} {str(k['shape']):22s} dev {k['dev']:.1e} at risk {k['n_risk']:5d} upstream params {len(k['upstream']) if k['upstream'] is not None else '(not traced)'}"
+            for k in risk]
+    return head + ("\n" + "\n".join(rows) if rows else "")
 
 
 # ---- bf16-storage emulation of the oracle: what ANY implementation that stores activations (and their gradients) in

@@ -39,8 +39,17 @@ def _check(z, model, pred, gt, forward=None, ref64=None):
             assert _rel(g_ref[k[5:]], z[k]) < 1e-7, k
     dev = (pred.detach().cpu().double() - ref).abs().max().item()
     floor = Fx.gradient_noise_floor(forward, sd64, in64, probe, g_ref, forward_dev=dev, pred_ref=ref)
-    tols = Fx.gradient_tolerances(floor)
-    worst = sorted(((_rel(grads[k], g) / tols[k], k) for k, g in g_ref.items()), reverse=True)
+    census = Fx.kink_census(forward, sd64, in64, forward_dev=dev, pred_ref=ref)
+    tols, risky = Fx.gradient_tolerances(floor, census)
+    print(Fx.describe_census(census))
+    print(f"{len(g_ref) - len(risky)} parameters have no at-risk kink downstream (held to 2 x their own floor), {len(risky)} have")
+    worst = []
+    for k, g in g_ref.items():
+        err = _rel(grads[k], g)
+        worst.append((err / tols[k], k))
+        if err > 2 * floor[k][1] + 1e-5:
+            print(f"  {k}: error {err:.2e} = {err / max(floor[k][1], 1e-30):.0f} x own floor {floor[k][1]:.1e}; at-risk kinks downstream: {risky.get(k, [])[:12]}")
+    worst.sort(reverse=True)
     assert worst[0][0] < 1.0, worst[:5]
 
 

@@ -140,3 +140,69 @@ def test_flat_adamw_checkpoint_round_trip_is_bit_exact(tmp_path):
     for pa, pc in zip(a.parameters(), c.parameters()):
         assert torch.equal(pa, pc)
     assert torch.equal(oa.exp_avg, oc.exp_avg) and torch.equal(oa.exp_avg_sq, oc.exp_avg_sq)
+
+
+def test_flat_adamw_exchanges_checkpoints_with_torch_adamw():
+    """The reference stores torch.optim.AdamW.state_dict() in its checkpoints (main.py:246-252) and resumes from it
+    (utils/utils.py:394).  Both directions: a torch-written state resumes here, a state written here
+    (state_dict(layout="torch")) resumes in torch; three more steps on either side must agree with the uninterrupted
+    run.  Second learning-rate group (diff_lr) included; a foreign dict raises a clear error."""
+    from jspsr_amd.ddp import GradReducer
+    from jspsr_amd.optim import FlatAdamW
+    torch.manual_seed(3)
+    mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.Conv2d(8, 8, 1), torch.nn.Conv2d(8, 5, 1)).cuda()
+    x = torch.randn(4, 3, 9, 9, device="cuda")
+
+    def torch_opt(net):
+        return torch.optim.AdamW([{"params": list(net[0].parameters()) + list(net[2].parameters())},
+                                  {"params": list(net[1].parameters()), "lr": 3e-4}], lr=1e-3, weight_decay=1e-6)
+
+    def flat_opt(net):
+        red = GradReducer(net.parameters())
+        return red, FlatAdamW(red, lr=1e-3, weight_decay=1e-6, lr_overrides={p: 3e-4 for p in net[1].parameters()})
+
+    def tsteps(net, opt, n):
+        for _ in range(n):
+            opt.zero_grad()
+            net(x).square().mean().backward()
+            opt.step()
+
+    def fsteps(net, red, opt, n):
+        for _ in range(n):
+            opt.zero_grad()
+            net(x).square().mean().backward()
+            red.finish()
+            opt.step()
+
+    ref = mk()
+    start = {k: v.clone() for k, v in ref.state_dict().items()}
+    ropt = torch_opt(ref)
+    tsteps(ref, ropt, 3)
+    import copy
+    mid_model, mid_opt = {k: v.clone() for k, v in ref.state_dict().items()}, copy.deepcopy(ropt.state_dict())    # (torch hands out its live tensors)
+    tsteps(ref, ropt, 3)                                     # the uninterrupted run: 6 steps
+    # torch checkpoint -> FlatAdamW
+    a = mk()
+    a.load_state_dict(mid_model)
+    ra, oa = flat_opt(a)
+    oa.load_state_dict(mid_opt)
+    assert oa.steps == 3
+    fsteps(a, ra, oa, 3)
+    for pa, pr in zip(a.parameters(), ref.parameters()):
+        assert torch.allclose(pa, pr, rtol=1e-5, atol=1e-7)
+    # FlatAdamW checkpoint (torch layout) -> torch
+    b = mk()
+    b.load_state_dict(start)
+    rb, ob = flat_opt(b)
+    fsteps(b, rb, ob, 3)
+    c = mk()
+    c.load_state_dict(b.state_dict())
+    copt = torch_opt(c)
+    copt.load_state_dict(ob.state_dict(layout="torch"))
+    tsteps(c, copt, 3)
+    for pc, pr in zip(c.parameters(), ref.parameters()):
+        assert torch.allclose(pc, pr, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError, match="unknown optimizer checkpoint format|not an optimizer state dict"):
+        oa.load_state_dict({"state": {}, "param_groups": [{"lr": 1e-3}]})
+    with pytest.raises(ValueError, match="groups its parameters differently"):
+        oa.load_state_dict(torch.optim.AdamW(mk().parameters()).state_dict())
