@@ -32,6 +32,8 @@
 // Out-of-image patch pixels fail the buffer descriptor's range check and land as zeros (the conv's zero padding).
 #include "conv_igemm.h"
 
+#include <atomic>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -64,10 +66,12 @@ constexpr int R_SCRP = 80;                                // scratch row pitch: 
 constexpr int R_SCRB = 64 * R_SCRP;                       // per wave
 constexpr int R_OFF_SCR = 2 * R_PATCHB;
 constexpr int R_OFF_RED = R_OFF_SCR + 8 * R_SCRB;         // [3][4][2][64] floats
-constexpr int R_LDS_STATS = R_OFF_RED + 3 * 4 * 2 * 64 * 4;
-constexpr int R_LDS_PLAIN = 2 * R_PATCHB;
+constexpr int R_RUNB = 16;                                // two published run starts of the dynamic tile queue (+ pad), last bytes of the segment
+constexpr int R_LDS_STATS = R_OFF_RED + 3 * 4 * 2 * 64 * 4 + R_RUNB;
+constexpr int R_LDS_PLAIN = 2 * R_PATCHB + R_RUNB;
 constexpr int R_OFF_PAR = 2 * R_PATCHB;                   // affine kernel: [2][64] floats, per-channel scale | bias
-constexpr int R_LDS_AFFINE = R_OFF_PAR + 2 * 64 * 4;
+constexpr int R_LDS_AFFINE = R_OFF_PAR + 2 * 64 * 4 + R_RUNB;
+constexpr int R_RUN = 4;                                  // tiles per claim of the dynamic queue (x-neighbours: incremental coordinates)
 #ifndef K2R_LA
 #define K2R_LA 4      // patch fragments requested ahead of their MFMA (lab builds: -DK2R_LA=n)
 #endif
@@ -106,8 +110,10 @@ __device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b, bool relu) {
 template <int SIGN, int MODE>      // MODE 0: plain, 1: + BatchNorm statistics, 2: + per-channel scale / bias
 __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt,
                                                                   const float* __restrict__ bias, __bf16* __restrict__ out,
-                                                                  float* __restrict__ stats, ConvGeom g, int ntiles) {
+                                                                  float* __restrict__ stats, ConvGeom g, int ntiles,
+                                                                  unsigned* __restrict__ ticket) {
   constexpr bool STATS = MODE == 1, AFFINE = MODE == 2;
+  constexpr int LDSB = MODE == 1 ? R_LDS_STATS : (MODE == 2 ? R_LDS_AFFINE : R_LDS_PLAIN);
   extern __shared__ __attribute__((aligned(128))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = (wave >> 1) & 3, wn = wave & 1;
@@ -428,8 +434,46 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   if constexpr (AFFINE) {      // absent scale -> 1, absent bias -> 0; visible to every wave after the first barrier of the loop
     if (tid < 128) reinterpret_cast<float*>(smem + R_OFF_PAR)[tid] = tid < 64 ? (g.scale ? g.scale[tid] : 1.f) : (bias ? bias[tid - 64] : 0.f);
   }
-  int t = v, it = 0;
-  Tile tcur{(v / ttx) / tty, (v / ttx) % tty, v % ttx}, tprev = tcur, tprev2 = tcur, tnext = advance(tcur);
+  // Tile walk.  Static (ticket == nullptr): tile v, v + G, v + 2G ... -- fine alone on the chip.  Dynamic: the workgroups
+  // draw runs of R_RUN x-neighbouring tiles from one global ticket, so a workgroup that got its CU late (a weight-gradient
+  // workgroup of another stream held the LDS) simply draws fewer runs instead of making the launch wait for its share.
+  // The draw is two tiles of latency away from its use: lane 0 issues the atomic when the walk ENTERS a run (for the
+  // run after the next), publishes the returned start in LDS one tile later (behind the vmcnt(0) this wave waits on
+  // anyway), and the barrier of the tile after that makes it visible -- R_RUN >= 3 tiles before it is needed.
+  const bool dyn = ticket != nullptr;
+  int* const s_run = reinterpret_cast<int*>(smem + LDSB - R_RUNB);
+  if (dyn) {
+    if (tid == 0) {
+      s_run[0] = (int)__hip_atomic_fetch_add(ticket, (unsigned)R_RUN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_run[1] = (int)__hip_atomic_fetch_add(ticket, (unsigned)R_RUN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+  auto tile_of = [&](int t_) { return Tile{(t_ / ttx) / tty, (t_ / ttx) % tty, t_ % ttx}; };
+  int t = dyn ? s_run[0] : v, it = 0;
+  int krun = 0, nrun = 0;                 // dynamic: position of tile t in its run, number of that run
+  int tn, kn, nn;                         // the same for the NEXT tile (tn >= ntiles: none)
+  unsigned pend = 0;                      // lane 0: a drawn run start not yet published
+  int pend_slot = -1;
+  auto step_walk = [&](int t_, int k_, int n_, Tile c_, int& t2, int& k2, int& n2, Tile& c2) {
+    if (!dyn) {
+      t2 = t_ + G; k2 = 0; n2 = 0; c2 = advance(c_);
+    } else if (k_ + 1 < R_RUN && t_ + 1 < ntiles) {
+      t2 = t_ + 1; k2 = k_ + 1; n2 = n_;
+      c2 = c_;
+      if (++c2.txi == ttx) { c2.txi = 0; if (++c2.tyi == tty) { c2.tyi = 0; ++c2.bimg; } }
+    } else {
+      n2 = n_ + 1; k2 = 0;
+      t2 = s_run[n2 & 1];                 // published at least one barrier ago
+      c2 = tile_of(t2 < ntiles ? t2 : 0);
+      if (tid == 0) {                     // entering run n2: draw run n2 + 1 into the slot run n2 - 1 no longer needs
+        pend = __hip_atomic_fetch_add(ticket, (unsigned)R_RUN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_slot = (n2 + 1) & 1;
+      }
+    }
+  };
+  Tile tcur = tile_of(t < ntiles ? t : 0), tprev = tcur, tprev2 = tcur, tnext;
+  step_walk(t, krun, nrun, tcur, tn, kn, nn, tnext);
   if (t < ntiles) {
     const PatchSrc p0 = patch_src(tcur);
     issue_patch(p0, 0);
@@ -441,7 +485,7 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
 #else
 #define K2R_STAMP(acc_) do { } while (0)
 #endif
-  for (; t < ntiles; t += G, ++it) {
+  for (; t < ntiles; ++it) {
     const int buf = it & 1;
 #ifdef K2R_STAMPS
     s0 = __builtin_readcyclecounter();
@@ -455,7 +499,7 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     if (STATS && stats && it > 1) flush_stats(tprev2, (it - 2) % 3);
     // Waves 0-3 request their pieces of the next patch before multiplying, waves 4-7 after writing their previous tile
     // out: either way a whole tap loop lies between the request and the wait.
-    const bool more = t + G < ntiles;
+    const bool more = tn < ntiles;
     const PatchSrc nxt = patch_src(tnext);
     if constexpr (ORDER == 0) {
     if (late) {
@@ -487,7 +531,11 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces (and, in waves 0-3, its stores)
     K2R_STAMP(st_vm);
     }
-    tprev2 = tprev; tprev = tcur; tcur = tnext; tnext = advance(tnext);
+    // (every vmcnt(0) above has passed: the drawn run start has returned) publish it, then move on one tile
+    if (dyn && tid == 0 && pend_slot >= 0 && pend_slot < 2) { s_run[pend_slot] = (int)pend; pend_slot += 2; }   // (+2: published; the slot number stays readable)
+    tprev2 = tprev; tprev = tcur; tcur = tnext;
+    t = tn; krun = kn; nrun = nn;
+    if (t < ntiles) step_walk(t, krun, nrun, tcur, tn, kn, nn, tnext);
     K2R_STAMP(st_post);
   }
 #ifdef K2R_STAMPS
@@ -495,6 +543,17 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
     printf("K2R wave %d tiles %d: barrier %llu  pre-mfma %llu  mfma %llu  vmcnt %llu  post-mfma %llu (cycles per tile)\n", wave, it,
            st_bar / it, st_pre / it, st_mfma / it, st_vm / it, st_post / it);
 #endif
+  if (dyn && tid == 0) {
+    // last workgroup out re-arms the ticket for the launch that gets this slot next (1024 launches from now).  Every
+    // draw of this workgroup has returned before it signs off (a straggling add after the reset would cost the next
+    // user its first run).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)G - 1u) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   if (late && it > 0) epilogue(tprev, (it - 1) % 3);
   if (STATS && stats && it > 0) {
     __syncthreads();
@@ -503,9 +562,27 @@ __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __
   }
 }
 
+// Tickets of the dynamic tile queue: (next tile, workgroups done) pairs, handed out round-robin per launch; the last
+// workgroup of a launch zeroes its pair again, and a slot comes round after 1024 launches.
+__device__ unsigned k2r_ring[2 * 1024];
+
+unsigned* next_ticket() {
+  static unsigned* base = [] {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(k2r_ring)) == hipSuccess ? static_cast<unsigned*>(p) : nullptr;
+  }();
+  static std::atomic<unsigned> n{0};
+  return base ? base + 2 * (n.fetch_add(1, std::memory_order_relaxed) % 1024u) : nullptr;
+}
+
 template <int SIGN, int MODE>
 void launch_k2r(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, int ntiles, int grid,
                 hipStream_t s) {
+  // dynamic tile queue (opt-in: JSPSR_CONV_DYNQ=1), once every workgroup has several runs to draw.  Measured in the
+  // multi-stream step on one box, three interleaved runs each: 65.9 / 64.2 / 65.5 ms static, 68.0 / 66.3 / 65.4 ms dynamic
+  // (profiles/r03_k2r_dynamic_queue_ab.txt) -- the late workgroups the queue relieves were not what the step waits for.
+  static const int dynq = [] { const char* e = getenv("JSPSR_CONV_DYNQ"); return e ? atoi(e) : 0; }();
+  unsigned* ticket = (dynq && (long long)ntiles >= 4LL * R_RUN * grid) ? next_ticket() : nullptr;
   constexpr int lds = MODE == 1 ? R_LDS_STATS : (MODE == 2 ? R_LDS_AFFINE : R_LDS_PLAIN);
   static bool attr_set = false;
   if (!attr_set) {
@@ -513,7 +590,7 @@ void launch_k2r(const void* in, const void* wgt, const float* bias, void* out, f
     attr_set = true;
   }
   hipLaunchKernelGGL((conv64_resident_kernel<SIGN, MODE>), dim3(grid), dim3(R_NTH), lds, s, static_cast<const __bf16*>(in),
-                     static_cast<const __bf16*>(wgt), bias, static_cast<__bf16*>(out), stats, g, ntiles);
+                     static_cast<const __bf16*>(wgt), bias, static_cast<__bf16*>(out), stats, g, ntiles, ticket);
 }
 
 }  // namespace

@@ -17,6 +17,16 @@
 // prop.hip.
 #include "prop_tile.h"
 
+#include <initializer_list>
+
+namespace jspsr {   // prop_head_dma.hip: the persistent LDS-DMA form for bf16 heads (what the benchmarked step runs)
+bool prop_head_dma_ok(int B, int H, int W, std::initializer_list<const void*> ptrs);
+int prop_head_dma_forward(const float* dem, const void* head, const float* wk, const float* b0, float scale, float* out, int B,
+                          int H, int W, hipStream_t s);
+int prop_head_dma_backward(const float* gout, const float* dem, const void* head, const float* wk, void* ghead, float* partial,
+                           int B, int H, int W, hipStream_t s);
+}  // namespace jspsr
+
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -241,8 +251,9 @@ __global__ __launch_bounds__(NT) void prop_head_kernel(const float* __restrict__
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) v += red[w][threadIdx.x];
-    partial[(size_t)blockIdx.x * NRED + threadIdx.x] = v;
+    partial[4 + (size_t)blockIdx.x * NRED + threadIdx.x] = v;      // behind the 16-byte header (row count)
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(partial)[0] = (int)gridDim.x;
 }
 
 int make_hgeom(int B, int H, int W, HGeom& g) {
@@ -270,6 +281,8 @@ extern "C" int jspsr_prop_head_forward(int dtype, const float* dem, const void* 
   if (!jspsr::aligned4(dem) || !jspsr::aligned4(out)) return jspsr::fail(JSPSR_EALIGN, "prop_head_forward: pointer not 4-byte aligned");
   g.dem_vec4 = (W % 4 == 0) && jspsr::aligned16(dem);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == JSPSR_BF16 && jspsr::prop_head_dma_ok(B, H, W, {dem, head, out}))
+    return jspsr::prop_head_dma_forward(dem, head, wk, b0, scale, out, B, H, W, s);
   if (dtype == JSPSR_F32)
     hipLaunchKernelGGL((prop_head_kernel<float, false>), dim3(g.nblk), dim3(NT), 0, s, dem, static_cast<const float*>(head), wk,
                        b0, scale, out, nullptr, nullptr, nullptr, g);
@@ -282,7 +295,8 @@ extern "C" int jspsr_prop_head_forward(int dtype, const float* dem, const void* 
 extern "C" size_t jspsr_prop_head_backward_workspace_bytes(int B, int H, int W) {
   HGeom g;
   if (make_hgeom(B, H, W, g)) return 0;
-  return ((size_t)g.nblk * NRED * sizeof(float) + 15) & ~(size_t)15;
+  const size_t rows = g.nblk > 4096 ? (size_t)g.nblk : 4096;          // the DMA form's grid is capped at 4096 workgroups
+  return 16 + ((rows * NRED * sizeof(float) + 15) & ~(size_t)15);      // header (row count) + rows, whichever kernel runs
 }
 
 extern "C" int jspsr_prop_head_backward(int dtype, const float* grad_out, const float* dem, const void* head,
@@ -299,6 +313,12 @@ extern "C" int jspsr_prop_head_backward(int dtype, const float* grad_out, const 
   g.dem_vec4 = (W % 4 == 0) && jspsr::aligned16(dem);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
+  if (dtype == JSPSR_BF16 && jspsr::prop_head_dma_ok(B, H, W, {grad_out, dem, head, grad_head})) {
+    if (int e = jspsr::prop_head_dma_backward(grad_out, dem, head, wk, grad_head, partial, B, H, W, s)) return e;
+    if (!grad_wk) return JSPSR_OK;
+    hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, -1, grad_wk, grad_b0);
+    return jspsr::check_launch("prop_head_backward_finalize");
+  }
   if (dtype == JSPSR_F32)
     hipLaunchKernelGGL((prop_head_kernel<float, true>), dim3(g.nblk), dim3(NT), 0, s, dem, static_cast<const float*>(head), wk,
                        nullptr, 0.f, nullptr, grad_out, static_cast<float*>(grad_head), partial, g);
@@ -307,6 +327,6 @@ extern "C" int jspsr_prop_head_backward(int dtype, const float* grad_out, const 
                        nullptr, 0.f, nullptr, grad_out, static_cast<__bf16*>(grad_head), partial, g);
   if (int e = jspsr::check_launch("prop_head_backward")) return e;
   if (!grad_wk) return JSPSR_OK;
-  hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, g.nblk, grad_wk, grad_b0);
+  hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, -1, grad_wk, grad_b0);
   return jspsr::check_launch("prop_head_backward_finalize");
 }
