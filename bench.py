@@ -90,18 +90,26 @@ def time_k1(model, inputs, iters=20):
         ops.prop_backward_raw(gout, dem, sets[i % nset][0], sets[i % nset][1], w, gsets[i % nset][0],
                               gsets[i % nset][1], gw, gb, ws)
 
-    res = {}
+    def timed(fn, reps=3):
+        """Mean launch duration (s) of `iters` back-to-back launches between two events on the launch stream; the MEDIAN of
+        `reps` such measurements (the first block after the training loop can run at a different clock), all reps kept."""
+        out = []
+        for _ in range(reps):
+            for i in range(3):
+                fn(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(iters):
+                fn(i)
+            e1.record()
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1) / iters * 1e-3)
+        return sorted(out)[len(out) // 2], [round(v * 1e6, 2) for v in out]
+
+    res, reps = {}, {}
     for name, fn in (("fwd", fwd), ("bwd", bwd), ("bwd_call", bwd_call)):
-        for i in range(3):
-            fn(i)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(iters):
-            fn(i)
-        e1.record()
-        e1.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters * 1e-3
+        res[name], reps[name] = timed(fn)
     # K1h: the entry the model itself uses (operands straight from the merged head's 32-channel NHWC output, in the
     # model's storage dtype): same timing rules.  Two byte counts per launch: `moved` = what the layout makes the kernel
     # touch (32 channels, 7 of them padding / the centre logit), `algorithmic` = the 25 operand elements + dem + out
@@ -126,16 +134,7 @@ def time_k1(model, inputs, iters=20):
                                                 B, H, W, st()), "jspsr_prop_head_backward")
 
     for name, fn in (("hfwd", hfwd), ("hbwd", hbwd)):
-        for i in range(3):
-            fn(i)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(iters):
-            fn(i)
-        e1.record()
-        e1.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters * 1e-3
+        res[name], reps[name] = timed(fn)
     # K1s: the general step of N-iteration chains (NLSPN, models/components/nlspn.py:177-233): raw affinities, gradients
     # ADDED into the shared affinity / offset gradients, and the gradient with respect to the raster (LDS scatter + float
     # atomics).  One step each way; algorithmic bytes = K1's + 4 B/px of grad_dem (+ the read of the accumulators).
@@ -151,16 +150,9 @@ def time_k1(model, inputs, iters=20):
         O._step_backward(gout, dem, sets[i % nset][0], sets[i % nset][1], ones9, 0.0, 0, 1, gsets[i % nset][0], gsets[i % nset][1], gdem, sws)
 
     for name, fn in (("sfwd", sfwd), ("sbwd", sbwd)):
-        for i in range(3):
-            fn(i)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(iters):
-            fn(i)
-        e1.record()
-        e1.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters * 1e-3
+        res[name], reps[name] = timed(fn, 1)
+    pmc_path = os.path.join(ROOT, "profiles", "k1_pmc.json")
+    traffic_names = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
     px = B * H * W
     steps_entry = {
         "kernel": "prop_step_fwd_kernel / prop_step_bwd_kernel (K1s, csrc/prop_steps.hip)",
@@ -170,7 +162,9 @@ def time_k1(model, inputs, iters=20):
                 "the 25 gradient planes it adds into (100 B/px) and adds grad_dem by float atomics (4 B/px each way) on top of K1's 208",
     }
     head = {
-        "kernel": f"prop_head_kernel<{'bf16' if es == 2 else 'f32'}>", "dtype": "bf16" if es == 2 else "f32",
+        "kernel": (traffic_names.get("head_bf16_fwd_kernel", "prop_head_dma_kernel<4, false, true>") + " / " +
+                   traffic_names.get("head_bf16_bwd_kernel", "prop_head_dma_kernel<4, true, true>")) if es == 2 else "prop_head_kernel<float, false|true>",
+        "dtype": "bf16" if es == 2 else "f32",
         "fwd_us": round(res["hfwd"] * 1e6, 2), "bwd_us": round(res["hbwd"] * 1e6, 2),
         "fwd_moved_GBs": round((32 * es + 8.0) * px / res["hfwd"] / 1e9, 1), "bwd_moved_GBs": round((64 * es + 8.0) * px / res["hbwd"] / 1e9, 1),
         "fwd_algorithmic_GBs": round((25 * es + 8.0) * px / res["hfwd"] / 1e9, 1),
@@ -204,11 +198,11 @@ def time_k1(model, inputs, iters=20):
         "bound": "hbm", "kernel": kname("bwd"), "achieved": round(bw_b, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bw_b / HBM_PEAK_GBS, 4),
         "traffic": traffic.get("bwd_bytes_per_launch") if traffic else None,
-        "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2),
+        "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2), "us_per_launch_reps": reps["bwd"],
         "us_per_call_with_fold": round(res["bwd_call"] * 1e6, 2),
         "forward": {"kernel": kname("fwd"), "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get("fwd_bytes_per_launch") if traffic else None,
-                    "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2)},
+                    "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2), "us_per_launch_reps": reps["fwd"]},
         "kernel_in_model": in_model["kernel"], "in_model": in_model,
         "head_entry": head,
         "steps_entry": steps_entry,

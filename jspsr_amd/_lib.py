@@ -94,6 +94,10 @@ def load():
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). jspsr_amd has no fallback path."
             )
+        # torch first: its bundled HIP runtime must be the one this process initialises -- libjspsr_hip.so binds to whatever
+        # libamdhip64 is loaded already, and loaded BEFORE torch it would pull in the system copy, leaving the process with
+        # two runtimes (seen as "no ROCm-capable device" on the first launch)
+        import torch  # noqa: F401
         lib = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so is stale

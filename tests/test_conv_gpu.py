@@ -413,10 +413,10 @@ def test_conv_epilogue_statistics(dtype, B, H, W, Cin, Cout, k, stride, pad):
 
 
 @pytest.mark.parametrize("env", [{"JSPSR_CONV_TALL": "2"}, {"JSPSR_CONV_NOPATCH": "1"}, {"JSPSR_WGRAD_NOPATCH": "1"},
-                                 {"JSPSR_CONV_TALL": "0"}, {"JSPSR_CONV_RESIDENT": "0"}])
+                                 {"JSPSR_CONV_TALL": "0"}, {"JSPSR_CONV_RESIDENT": "0"}, {"JSPSR_CONV_DYNQ": "1"}])
 def test_opt_in_kernel_variants_in_a_child_process(env):
     """The library reads its lab switches once per process: the opt-in / fallback instantiations (8-wave 256x128 tile,
-    generic implicit-GEMM kernel only, generic weight-gradient kernel only, no 16x16 tile, no register-resident 64-channel kernel) are exercised in a child
+    generic implicit-GEMM kernel only, generic weight-gradient kernel only, no 16x16 tile, no register-resident 64-channel kernel, K2r's dynamic tile queue) are exercised in a child
     process against the same fp64 reference, so that they stay correct while they are not the default."""
     import subprocess
     import sys
@@ -424,7 +424,9 @@ def test_opt_in_kernel_variants_in_a_child_process(env):
 import torch, torch.nn.functional as F
 from jspsr_amd import kernels as K
 g = torch.Generator().manual_seed(0)
-for (B, H, W, Ci, Co) in [(2, 256, 256, 64, 128), (4, 256, 256, 64, 64)]:
+for (B, H, W, Ci, Co) in [(2, 256, 256, 64, 128), (4, 256, 256, 64, 64), (8, 512, 512, 64, 64)]:   # (the last: the dynamic tile queue's size)
+    if B == 8 and not __import__("os").environ.get("JSPSR_CONV_DYNQ"):
+        continue
     x = torch.randn(B, Ci, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).bfloat16().float()
     go = torch.randn(B, Co, H, W, generator=g).bfloat16().float()

@@ -118,3 +118,4 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["global_tiles"] == 2
+    assert out["cpu_baseline"] and out["cpu_baseline"]["value"] > 0        # rank 0 times the CPU oracle at every N (north_star: "in the same run")

@@ -83,6 +83,10 @@ def test_golden_fixture(golden_dir, oc):
     ((1, 129, 260), 8.0, 18),    # stress: most taps leave tile+halo -> global fallback
     ((1, 64, 64), 0.0, 16),      # zero offsets: plain 3x3 window
     ((2, 5, 3), 3.0, 16),        # tiny raster, taps mostly outside
+    ((2, 6, 132), 1.5, 16),      # LDS-DMA path: H % 4 != 0 (a tile row with idle waves), W = 2 tiles + 4 pixels
+    ((1, 3, 64), 2.0, 18),       # LDS-DMA path: fewer rows than a tile, 18-channel offsets
+    ((5, 20, 72), 1.5, 16),      # LDS-DMA path: a workgroup's run crosses images
+    ((1, 260, 1028), 1.5, 16),   # LDS-DMA path: more tiles than workgroups (persistent runs of several tiles, ragged both ways)
 ])
 def test_random_cases(shape, sigma, oc):
     case = _rand_case(*shape, sigma, seed=sum(shape) + int(sigma * 10))
@@ -92,7 +96,8 @@ def test_random_cases(shape, sigma, oc):
         exp[2] = exp[2].clone()
         exp[2][:, 8:10] = 0
     # fp32 coordinates: ulp(p) ~ 4e-6 at |p| ~ 50 px times the white-noise DEM's unit slope
-    tol = 2e-5 if sigma <= 3 else 1e-4
+    # (|p| ~ 1000 px: ulp(p) = 6e-5, times |grad_out| up to 4.5 and a tap weight up to 1.6 in the gradients)
+    tol = (2e-5 if sigma <= 3 else 1e-4) if max(shape) <= 300 else 4e-4
     _close(got[0], exp[0], 1e-5, tol, "out")
     _close(got[1], exp[1], 1e-5, tol, "grad_weight")
     # d/d(offset) of a bilinear sample jumps at integer coordinates: skip samples whose fp32
@@ -110,6 +115,81 @@ def test_random_cases(shape, sigma, oc):
     assert sigma == 0 or smooth.double().mean() > 0.85  # the centre tap (offset 0) always sits on a kink
     _close(got[3], exp[3], 1e-4, 5e-4, "grad_w")
     _close(got[4], exp[4], 1e-5, 5e-4, "grad_b")
+
+
+def _census(names):
+    from jspsr_amd import _lib
+    lib = _lib.load()
+    return {n: lib.jspsr_launch_count(n.encode()) for n in names}
+
+
+def test_dma_and_general_kernels_are_selected_by_shape():
+    """Rows of 16-byte-aligned operands with W % 4 == 0 take the persistent LDS-DMA kernels (prop_dma.hip, prop_head_dma.hip
+    for bf16 heads); anything else the general kernels -- asserted from the library's launch census, so the parity cases
+    above are known to cover both."""
+    ops = _ops()
+    names = ("prop_forward (dma)", "prop_backward (dma)", "prop_forward", "prop_backward",
+             "prop_head_forward (dma)", "prop_head_backward (dma)", "prop_head_forward", "prop_head_backward")
+    for shape, dma in (((2, 40, 100), True), ((2, 37, 53), False)):
+        case = _rand_case(*shape, 1.5, seed=11)
+        before = _census(names)
+        _run_hip(*case, oc=16)
+        d = {k: v - before[k] for k, v in _census(names).items()}
+        assert (d["prop_forward (dma)"], d["prop_backward (dma)"], d["prop_forward"], d["prop_backward"]) == ((1, 1, 0, 0) if dma else (0, 0, 1, 1)), d
+        B, H, W = shape
+        for dtype, hd in ((torch.bfloat16, dma), (torch.float32, False)):
+            head = torch.randn(B, H, W, 32).to(dtype).cuda().requires_grad_()
+            before = _census(names)
+            ops.propagate_head(case[0].cuda(), head, case[3].cuda(), case[4].cuda(), 1.0).sum().backward()
+            d = {k: v - before[k] for k, v in _census(names).items()}
+            assert (d["prop_head_forward (dma)"], d["prop_head_backward (dma)"], d["prop_head_forward"], d["prop_head_backward"]) == \
+                ((1, 1, 0, 0) if hd else (0, 0, 1, 1)), (dtype, d)
+
+
+@pytest.mark.parametrize("env", [{"JSPSR_PROP_SPLIT": "0", "JSPSR_PROP_HEAD_SPLIT": "0"}, {"JSPSR_PROP_SPLIT": "1", "JSPSR_PROP_NW": "8"},
+                                 {"JSPSR_PROP_NTL": "0", "JSPSR_PROP_WGS": "1", "JSPSR_PROP_HEAD_WGS": "1"},
+                                 {"JSPSR_PROP_DMA": "0", "JSPSR_PROP_HEAD_DMA": "0"}])
+def test_other_forms_of_the_dma_kernels_in_a_child_process(env):
+    """The library reads its switches once per process.  The defaults run the forward with mover / compute waves and the
+    backward with symmetric waves (NW = 4, non-temporal loads); the other instantiations -- both directions in either
+    form, 8-row tiles, default-policy loads, one workgroup per CU, and the general kernels on DMA-eligible shapes -- must
+    stay correct too: same fp64 oracle, same tolerances, in a child process per setting."""
+    import subprocess
+    import sys
+    code = r"""
+import torch
+from oracle import jspsr_ref as R
+from tests.test_prop_gpu import _rand_case, _run_hip, _run_oracle64, _close, _head_case
+from jspsr_amd import ops
+for shape, oc in (((2, 40, 100), 16), ((1, 6, 132), 18), ((3, 64, 192), 16)):
+    case = _rand_case(*shape, 1.5, seed=sum(shape))
+    got, exp = _run_hip(*case, oc=oc), list(_run_oracle64(*case))
+    if oc == 16:
+        exp[2] = exp[2].clone(); exp[2][:, 8:10] = 0
+    _close(got[0], exp[0], 1e-5, 2e-5, "out"); _close(got[1], exp[1], 1e-5, 2e-5, "grad_weight")
+    off = case[2].double(); B, _, H, W = off.shape
+    pos = off.clone(); pos[:, 0::2] += torch.arange(H, dtype=torch.float64).view(1, 1, H, 1); pos[:, 1::2] += torch.arange(W, dtype=torch.float64).view(1, 1, 1, W)
+    smooth = ((pos - pos.round()).abs().reshape(B, 9, 2, H, W).amin(2, keepdim=True) > 1e-4).expand(B, 9, 2, H, W).reshape(B, 18, H, W)
+    _close(got[2] * smooth, exp[2] * smooth, 1e-4, 4e-5, "grad_offset")
+    _close(got[3], exp[3], 1e-4, 5e-4, "grad_w"); _close(got[4], exp[4], 1e-5, 5e-4, "grad_b")
+dem, head, weight, offset, w, b, gout = _head_case(2, 24, 136, torch.bfloat16, seed=5)
+hd = head.cuda().requires_grad_()
+out = ops.propagate_head(dem.float().cuda(), hd, w.float().cuda(), b.float().cuda(), 1.0)
+out.backward(gout.float().cuda())
+h64 = head.double().requires_grad_()
+lg, o16 = ops.split_head(h64)
+o16 = o16.permute(0, 3, 1, 2)
+ref = R.propagate(dem, torch.sigmoid(lg).permute(0, 3, 1, 2), torch.cat((o16[:, :8], torch.zeros(2, 2, 24, 136, dtype=torch.float64), o16[:, 8:]), 1), w, b)
+ref.backward(gout)
+assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 5e-6
+h5 = head.double().view(2, 24, 136, 8, 4)
+sm = (h5[..., 1:3] != h5[..., 1:3].round()).all(-1, keepdim=True).expand(2, 24, 136, 8, 4).reshape(2, 24, 136, 32).double()
+assert (((hd.grad.cpu().double() - h64.grad) * sm).norm() / h64.grad.norm()).item() < 2.0 ** -8
+print("forms ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                       timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "forms ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_matches_c_oracle_fp32_bitclose():
@@ -244,7 +324,7 @@ def _head_case(B, H, W, dtype, seed, sigma=2.0):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 13, 70), (3, 8, 64), (1, 1, 1), (2, 40, 129)])
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 13, 70), (3, 8, 64), (1, 1, 1), (2, 40, 129), (2, 6, 132), (1, 70, 200)])
 def test_head_entry_matches_oracle(B, H, W, dtype):
     """Forward and backward of the head-fed kernel against the fp64 oracle evaluated on the SAME stored head values
     (sigmoid and zero centre offset applied by the oracle as the reference's Generator does, spn.py:43,69-73).  Ragged
@@ -271,7 +351,8 @@ def test_head_entry_matches_oracle(B, H, W, dtype):
     gh, gr = head_d.grad.cpu().double(), head64.grad
     # d/d(offset) jumps at integer sampling positions and where a tap crosses the raster border: compare off that set
     h5 = head.double().view(B, H, W, 8, 4)
-    smooth = (h5[..., 1:3] != h5[..., 1:3].round()).all(-1, keepdim=True).expand(B, H, W, 8, 4).reshape(B, H, W, 32).double()
+    # (within 1e-4 of an integer: the fp32 coordinate may land on the other side of the kink)
+    smooth = ((h5[..., 1:3] - h5[..., 1:3].round()).abs() > 1e-4).all(-1, keepdim=True).expand(B, H, W, 8, 4).reshape(B, H, W, 32).double()
     if dtype == torch.float32:
         assert ((gh - gr) * smooth).abs().max().item() < 2e-5 * gr.abs().max().item() + 1e-7
     else:

@@ -46,10 +46,14 @@ def main():
         out[f"{name}_write_kib"] = round(Wr[k], 1)
         out[f"{name}_bytes_per_launch"] = int(round((2 * F[k] + Wr[k]) * 1024))
         out[f"{name}_algorithmic_bytes"] = (108 if name == "fwd" else 208) * px
-    # K1h: prop_head_kernel<T, BWD>
+    # K1h: prop_head_dma_kernel<NW, BWD, SPLIT> (bf16 heads: what the models launch), prop_head_kernel<T, BWD> (fp32 heads)
     for dt, es, pat in (("bf16", 2, "__bf16"), ("f32", 4, "float")):
         for name, bwd in (("fwd", "false"), ("bwd", "true")):
             ks = [k for k in F if re.search(r"prop_head_kernel<%s, %s>" % (pat, bwd), k)]
+            if dt == "bf16":
+                ks = [k for k in F if re.search(r"prop_head_dma_kernel<\d+, %s, " % bwd, k)] or ks
+                if ks:
+                    out[f"head_bf16_{name}_kernel"] = re.search(r"prop_head(_dma)?_kernel<[^>]*>", ks[0]).group(0)
             if not ks or ks[0] not in Wr:
                 continue
             k = ks[0]

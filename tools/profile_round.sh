@@ -9,9 +9,9 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $root/bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
 echo "[profile] bench line done"
-rocprofv3 --kernel-trace --stats -f csv -d $out/step -o step -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline > $out/step.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $out/step -o step -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline --no-inference > $out/step.log 2>&1
 echo "[profile] multi-stream step traced"
-JSPSR_BRANCH_STREAMS=0 JSPSR_WGRAD_ASYNC=0 rocprofv3 --kernel-trace --stats -f csv -d $out/step1s -o step1s -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline > $out/step1s.log 2>&1
+JSPSR_BRANCH_STREAMS=0 JSPSR_WGRAD_ASYNC=0 rocprofv3 --kernel-trace --stats -f csv -d $out/step1s -o step1s -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline --no-inference > $out/step1s.log 2>&1
 echo "[profile] single-stream step traced"
 rocprofv3 --kernel-trace --stats -f csv -d $out/k1 -o k1 -- python3 $root/tools/k1_lab.py > $out/k1.log 2>&1
 echo "[profile] K1 micro-benchmark traced"
@@ -24,6 +24,7 @@ python3 tools/kstats.py $out/step1s 45 > $out/step1s_kernel_stats.txt
 python3 tools/kstats.py $out/k1 12 > $out/k1_kernel_stats.txt
 python3 tools/pmc_summary.py $out/k1_fetch prop > $out/k1_pmc_counters.txt
 python3 tools/pmc_summary.py $out/k1_write prop >> $out/k1_pmc_counters.txt
+python3 tools/k1_pmc_json.py $out/k1_fetch $out/k1_write "round ${tag#r}" > $out/k1_pmc.json
 f=$(find $out/step1s -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/ktrace.py $f 45 > $out/step1s_per_grid.txt
 # keep the merged-back volume small: summaries only
 find $out \( -name "*.db" -o -name "*.csv" -size +2M \) -delete
