@@ -77,12 +77,17 @@ def test_model_matches_reference_fixture(golden_dir, name, ic):
     tols, risky = Fx.gradient_tolerances(floor, census)
     print(f"{name}: " + Fx.describe_census(census))
     print(f"{name}: {len(g_ref) - len(risky)} parameters have no at-risk kink downstream (held to 2 x their own floor), {len(risky)} have")
-    worst = []
+    worst, by_floor = [], []
     for k, ref_g in g_ref.items():
         err = _rel(grads[k], ref_g)
         worst.append((err / tols[k], k, err, tols[k]))
-        if err > 2 * floor[k][1] + 1e-5:      # beyond its own floor: must be explained by a listed kink (else the assert below fires)
-            print(f"  {k}: error {err:.2e} = {err / max(floor[k][1], 1e-30):.0f} x own floor {floor[k][1]:.1e}; at-risk kinks downstream: {risky.get(k, [])[:12]}")
+        by_floor.append((err / max(floor[k][1], 1e-30), k, err))
+    by_floor.sort(reverse=True)
+    for ratio, k, err in by_floor[:3]:      # the parameters furthest above their OWN floor, and the at-risk kinks that explain it
+        print(f"  {k}: error {err:.2e} = {ratio:.1f} x own floor {floor[k][1]:.1e}; at-risk kinks downstream: {len(risky.get(k, []))} {risky.get(k, [])[:12]}")
+        assert err <= 2 * floor[k][1] + 1e-5 or k in risky, (k, ratio)        # beyond its own floor only if a listed kink can explain it
+    for k in ("layer3d.dconv.bn.bias",):      # the round-2 outlier of this architecture (146 x its floor on one run)
+        print(f"  {k}: at-risk kinks downstream: {len(risky.get(k, []))} {risky.get(k, [])[:12]}")
     worst.sort(reverse=True)
     print(f"{name}: worst gradient error / derived tolerance: " + "; ".join(f"{k} {e:.2e}/{t:.2e}" for _, k, e, t in worst[:4]))
     assert worst[0][0] < 1.0, worst[:5]

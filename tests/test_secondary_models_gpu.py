@@ -43,12 +43,18 @@ def _check(z, model, pred, gt, forward=None, ref64=None):
     tols, risky = Fx.gradient_tolerances(floor, census)
     print(Fx.describe_census(census))
     print(f"{len(g_ref) - len(risky)} parameters have no at-risk kink downstream (held to 2 x their own floor), {len(risky)} have")
-    worst = []
+    worst, by_floor = [], []
     for k, g in g_ref.items():
         err = _rel(grads[k], g)
         worst.append((err / tols[k], k))
-        if err > 2 * floor[k][1] + 1e-5:
-            print(f"  {k}: error {err:.2e} = {err / max(floor[k][1], 1e-30):.0f} x own floor {floor[k][1]:.1e}; at-risk kinks downstream: {risky.get(k, [])[:12]}")
+        by_floor.append((err / max(floor[k][1], 1e-30), k, err))
+    by_floor.sort(reverse=True)
+    for ratio, k, err in by_floor[:3]:
+        print(f"  {k}: error {err:.2e} = {ratio:.1f} x own floor {floor[k][1]:.1e}; at-risk kinks downstream: {len(risky.get(k, []))} {risky.get(k, [])[:12]}")
+        assert err <= 2 * floor[k][1] + 1e-5 or k in risky, (k, ratio)
+    for k in ("layer3d.dconv.bn.bias", "weight_offset3.ref.bn1.bias"):      # the round-2 outliers (146 x / 134 x their floors)
+        if k in g_ref:
+            print(f"  {k}: at-risk kinks downstream: {len(risky.get(k, []))} {risky.get(k, [])[:12]}")
     worst.sort(reverse=True)
     assert worst[0][0] < 1.0, worst[:5]
 
