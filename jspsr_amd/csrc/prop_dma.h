@@ -15,11 +15,14 @@ constexpr int DW = 64;                 // tile width in pixels = one wave's row
 constexpr int DLW = DW + 2 * HALO;     // staged DEM row: 80 floats
 
 
-template <int NW, int OPB>                 // OPB: bytes of one row's operand buffer (whole 1 KiB DMA pieces)
+// NW waves (rows per pass), RP passes per tile: a tile is 64 x (NW RP) pixels and shares ONE staged DEM tile + halo.
+// OPB: bytes of one row's operand buffer (whole 1 KiB DMA pieces).
+template <int NW, int OPB, int RP = 1>
 struct DmaCfg {
-  static constexpr int LH = NW + 2 * HALO;
+  static constexpr int TH = NW * RP;
+  static constexpr int LH = TH + 2 * HALO;
   static constexpr int CHUNKS = LH * (DLW / 4);        // 16-byte chunks of the DEM tile
-  static constexpr int PIECES = (CHUNKS + 63) / 64;
+  static constexpr int PIECES = (CHUNKS + (DLW + 4) / 4 + 63) / 64;      // + a zero pad of one row + 2 behind the tile (gather_taps)
   static constexpr int DPW = (PIECES + NW - 1) / NW;   // DEM pieces per wave
   static constexpr int DEMB = PIECES * 1024;
   static constexpr int SMEM = 2 * DEMB + 2 * NW * OPB;

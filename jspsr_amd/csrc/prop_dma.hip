@@ -50,10 +50,10 @@ struct DmaArgs {
 // SPLIT = true:  NW compute waves (0 .. NW-1) + NW mover waves (NW .. 2 NW-1); mover NW + w loads what compute wave w
 //                consumes, so a compute wave never pays the issue time of an LDS-DMA instruction (200-400 cycles each
 //                while the memory pipeline is backed up), and the tile's bytes are requested as soon as the barrier falls.
-template <int OC, int NW, bool BWD, bool NTL, bool SPLIT>
+template <int OC, int NW, bool BWD, bool NTL, bool SPLIT, int RP>
 __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop_dma_kernel(const DmaArgs A) {
-  using C = DmaCfg<NW, OPB>;
-  constexpr int LH = C::LH;
+  using C = DmaCfg<NW, OPB, RP>;
+  constexpr int LH = C::LH, TH = C::TH;
   constexpr int NPL = 9 + OC + (BWD ? 1 : 0);      // operand planes staged per row
   constexpr int NPIECE = (NPL + 3) / 4;
   constexpr int NOUTPL = 9 + OC;                   // gradient planes written per row (backward)
@@ -109,31 +109,34 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
     dcx[j] = q < C::CHUNKS ? cc : (1 << 30);      // beyond the tile: never inside the raster (the DMA lands zeros: ZPAD)
   }
 
-  auto issue_tile = [&](int ib, int ity, int itx, int buf) __attribute__((always_inline)) {
-    const int y0 = ity * NW, x0 = itx * DW;
-    {
-      const unsigned long long db = reinterpret_cast<unsigned long long>(A.dem + (size_t)ib * P);
-      const i32x4 desc = i32x4{(int)(unsigned)db, (int)((unsigned)(db >> 32) & 0xffffu), (int)(unsigned)(P * 4), 0x00020000};
-      const int origin = ((y0 - HALO) * W + (x0 - HALO)) * 4;
+  // the DEM tile + halo of tile (ib, ity, itx) into DEM buffer `dbuf`: this wave's pieces
+  auto issue_dem = [&](int ib, int ity, int itx, int dbuf) __attribute__((always_inline)) {
+    const int y0 = ity * TH, x0 = itx * DW;
+    const unsigned long long db = reinterpret_cast<unsigned long long>(A.dem + (size_t)ib * P);
+    // (wave-uniform by construction; readfirstlane makes the compiler see it, or the descriptor lands in VGPRs)
+    const i32x4 desc = i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)db), __builtin_amdgcn_readfirstlane((int)((unsigned)(db >> 32) & 0xffffu)),
+                             __builtin_amdgcn_readfirstlane((int)(unsigned)(P * 4)), 0x00020000};
+    const int origin = ((y0 - HALO) * W + (x0 - HALO)) * 4;
 #pragma unroll
-      for (int j = 0; j < C::DPW; ++j) {
-        const int piece = wave + j * NW;
-        if (piece < C::PIECES) {     // wave-uniform
-          // rows above / below the raster fail the range check by themselves (negative or >= P*4); columns do not
-          const unsigned off = (unsigned)(x0 - HALO + dcx[j]) < (unsigned)W ? (unsigned)(origin + doff[j]) : 0xFFFFFFF0u;
-          const unsigned dst = lds0 + buf * C::DEMB + piece * 1024;
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(off), "s"(desc) : "memory");
-        }
+    for (int j = 0; j < C::DPW; ++j) {
+      const int piece = wave + j * NW;
+      if (piece < C::PIECES) {     // wave-uniform
+        // rows above / below the raster fail the range check by themselves (negative or >= P*4); columns do not
+        const unsigned off = (unsigned)(x0 - HALO + dcx[j]) < (unsigned)W ? (unsigned)(origin + doff[j]) : 0xFFFFFFF0u;
+        const unsigned dst = lds0 + dbuf * C::DEMB + piece * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(off), "s"(desc) : "memory");
       }
     }
-    const int y = y0 + wave;
+  };
+  // this wave's row y of image ib, 64 pixels from x0, into operand buffer `obuf`
+  auto issue_row = [&](int ib, int y, int x0, int obuf) __attribute__((always_inline)) {
     if (y < H) {       // wave-uniform
       const size_t pix = (size_t)y * W + x0;
       const char* wb = reinterpret_cast<const char*>(A.weight + (size_t)ib * 9 * P + pix);
       const char* ob = reinterpret_cast<const char*>(A.offset + (size_t)ib * OC * P + pix);
       const char* gb = BWD ? reinterpret_cast<const char*>(A.gout + (size_t)ib * P + pix) : wb;
       const bool colok = x0 + lc * 4 < W;
-      const unsigned dst0 = lds0 + 2 * C::DEMB + (buf * NW + wave) * OPB;
+      const unsigned dst0 = lds0 + 2 * C::DEMB + (obuf * NW + wave) * OPB;
 #pragma unroll
       for (int i = 0; i < NPIECE; ++i) {
         const int p = 4 * i + lq;
@@ -154,33 +157,48 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
 #pragma unroll
   for (int i = 0; i < NRED; ++i) dsum[i] = 0.f;
 
-  if (mover) issue_tile(b, ty, tx, 0);
+  // Slots: (tile t, pass p), p = 0 .. RP-1: rows ty TH + p NW + wave.  Operand buffers alternate per slot, DEM buffers per
+  // tile.  Symmetric waves meet at ONE barrier per tile (the DEM tile is the only shared data; within a tile every wave
+  // runs its RP rows at its own pace); split waves also hand rows from mover to compute wave, so they meet every slot.
+  if (mover) {
+    issue_dem(b, ty, tx, 0);
+    issue_row(b, ty * TH + wave, tx * DW, 0);
+  }
   bool counted = false;      // (not SPLIT) this wave issued NST stores behind the pieces it waits for next
-  int buf = 0;
+  int buf = 0, dbuf = 0;
 #pragma unroll 1
-  for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+  for (int t = t_begin; t < t_end; ++t, dbuf ^= 1) {
+    int nb = b, nty = ty, ntx = tx + 1;
+    if (ntx == A.tiles_x) { ntx = 0; if (++nty == A.tiles_y) { nty = 0; ++nb; } }
+#pragma unroll 1
+  for (int ps = 0; ps < RP; ++ps, buf ^= 1) {
     K1D_STAMP(5);
     if (mover) {
-      // this wave's pieces of tile t have landed (all but its NST younger stores of tile t-1)
+      // this wave's pieces of this slot have landed (all but its NST younger stores of the previous slot)
       if (!SPLIT && counted) wait_vm<NST>(); else wait_vm<0>();
     }
     K1D_STAMP(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous tile's LDS traffic is done (a raw barrier waits for nothing)
-    __builtin_amdgcn_s_barrier();
+    if (SPLIT || ps == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous slot's LDS traffic is done (a raw barrier waits for nothing)
+      __builtin_amdgcn_s_barrier();
+    }
     K1D_STAMP(1);
-    // tile t+1 into the other buffers: every wave is past its reads of them (tile t-1) -- it is past the barrier
-    int nb = b, nty = ty, ntx = tx + 1;
-    if (ntx == A.tiles_x) { ntx = 0; if (++nty == A.tiles_y) { nty = 0; ++nb; } }
-    if (mover && t + 1 < t_end) issue_tile(nb, nty, ntx, buf ^ 1);
+    // the next slot into the other operand buffer; at a tile's first pass also the NEXT tile's DEM tile into the other
+    // DEM buffer (every wave is past the barrier, i.e. past its reads of that buffer)
+    if (mover) {
+      if (ps == 0 && t + 1 < t_end) issue_dem(nb, nty, ntx, dbuf ^ 1);
+      if (ps + 1 < RP) issue_row(b, ty * TH + (ps + 1) * NW + wave, tx * DW, buf ^ 1);
+      else if (t + 1 < t_end) issue_row(nb, nty * TH + wave, ntx * DW, buf ^ 1);
+    }
     K1D_STAMP(2);
 
-    const int y0 = ty * NW, x0 = tx * DW;
-    const int y = y0 + wave, x = x0 + lane;
+    const int y0 = ty * TH, x0 = tx * DW;
+    const int y = y0 + ps * NW + wave, x = x0 + lane;
     counted = y < H;
     if (computes && y < H) {       // wave-uniform
       float* ob = reinterpret_cast<float*>(smem + 2 * C::DEMB + (buf * NW + wave) * OPB);
       if (x < W) {
-        const float* dl = reinterpret_cast<const float*>(smem + buf * C::DEMB);
+        const float* dl = reinterpret_cast<const float*>(smem + dbuf * C::DEMB);
         const float* img = A.dem + (size_t)b * P;
         const int ly0 = y0 - HALO, lx0 = x0 - HALO;
         float a[9];
@@ -281,6 +299,7 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
       }
     }
     K1D_STAMP(4);
+  }
     b = nb; ty = nty; tx = ntx;
   }
 #ifdef K1D_STAMPS
@@ -331,7 +350,7 @@ namespace jspsr { int prop_dma_max_rows(); }
 namespace {
 
 struct Plan {
-  int nw, grid;
+  int nw, rp, grid;
   bool ntl, split;
 };
 
@@ -342,12 +361,16 @@ Plan make_plan(int B, int H, int W, bool bwd, DmaArgs& A) {
   static const int split_env = env_int("JSPSR_PROP_SPLIT", -1);
   static const int wgs_env = env_int("JSPSR_PROP_WGS", 0);     // workgroups per CU (0 = what the LDS admits)
   Plan p;
+  static const int rp_env = env_int("JSPSR_PROP_RP", 0);        // rows per wave per tile (1, 2 or 4)
   p.nw = nw_env == 8 ? 8 : 4;
   p.ntl = ntl_env < 0 ? true : ntl_env != 0;
   p.split = split_env < 0 ? !bwd : split_env != 0;
+  // several rows per wave under one staged DEM tile: symmetric waves only (they then meet once per TILE; split waves hand
+  // rows over every slot anyway, and their 128-register budget has no room for the second loop level)
+  p.rp = (p.nw == 8 || p.split) ? 1 : (rp_env == 2 || rp_env == 4 ? rp_env : 1);      // measured equal within the noise (profiles/r03_k1_dma_rows_per_tile.txt): 1
   A.B = B; A.H = H; A.W = W;
   A.tiles_x = (W + DW - 1) / DW;
-  A.tiles_y = (H + p.nw - 1) / p.nw;
+  A.tiles_y = (H + p.nw * p.rp - 1) / (p.nw * p.rp);
   const long long n = (long long)B * A.tiles_x * A.tiles_y;
   A.ntiles = (int)n;
   const int per_cu = wgs_env > 0 ? wgs_env : (p.nw == 8 ? 1 : 2);
@@ -357,17 +380,26 @@ Plan make_plan(int B, int H, int W, bool bwd, DmaArgs& A) {
   return p;
 }
 
-template <int OC, bool BWD, int NW, bool NTL>
-void launch3(const Plan& p, const DmaArgs& A, hipStream_t s) {
+template <int OC, bool BWD, int NW, bool NTL, int RP>
+void launch4(const Plan& p, const DmaArgs& A, hipStream_t s) {
   const dim3 grid(p.grid);
-  if (p.split) hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, true>), grid, dim3(2 * NW * 64), 0, s, A);
-  else         hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, false>), grid, dim3(NW * 64), 0, s, A);
+  if constexpr (RP == 1) {
+    if (p.split) { hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, true, 1>), grid, dim3(2 * NW * 64), 0, s, A); return; }
+  }
+  hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, false, RP>), grid, dim3(NW * 64), 0, s, A);
+}
+
+template <int OC, bool BWD, bool NTL>
+void launch3(const Plan& p, const DmaArgs& A, hipStream_t s) {
+  if (p.nw == 8) launch4<OC, BWD, 8, NTL, 1>(p, A, s);
+  else if (p.rp == 4) launch4<OC, BWD, 4, NTL, 4>(p, A, s);
+  else if (p.rp == 2) launch4<OC, BWD, 4, NTL, 2>(p, A, s);
+  else launch4<OC, BWD, 4, NTL, 1>(p, A, s);
 }
 
 template <int OC, bool BWD>
 void launch(const Plan& p, const DmaArgs& A, hipStream_t s) {
-  if (p.nw == 8) { if (p.ntl) launch3<OC, BWD, 8, true>(p, A, s); else launch3<OC, BWD, 8, false>(p, A, s); }
-  else           { if (p.ntl) launch3<OC, BWD, 4, true>(p, A, s); else launch3<OC, BWD, 4, false>(p, A, s); }
+  if (p.ntl) launch3<OC, BWD, true>(p, A, s); else launch3<OC, BWD, false>(p, A, s);
 }
 
 }  // namespace

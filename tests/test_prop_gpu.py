@@ -148,11 +148,13 @@ def test_dma_and_general_kernels_are_selected_by_shape():
 
 @pytest.mark.parametrize("env", [{"JSPSR_PROP_SPLIT": "0", "JSPSR_PROP_HEAD_SPLIT": "0"}, {"JSPSR_PROP_SPLIT": "1", "JSPSR_PROP_NW": "8"},
                                  {"JSPSR_PROP_NTL": "0", "JSPSR_PROP_WGS": "1", "JSPSR_PROP_HEAD_WGS": "1"},
-                                 {"JSPSR_PROP_DMA": "0", "JSPSR_PROP_HEAD_DMA": "0"}])
+                                 {"JSPSR_PROP_DMA": "0", "JSPSR_PROP_HEAD_DMA": "0"},
+                                 {"JSPSR_PROP_SPLIT": "0", "JSPSR_PROP_RP": "2"}, {"JSPSR_PROP_SPLIT": "0", "JSPSR_PROP_RP": "4"}])
 def test_other_forms_of_the_dma_kernels_in_a_child_process(env):
     """The library reads its switches once per process.  The defaults run the forward with mover / compute waves and the
     backward with symmetric waves (NW = 4, non-temporal loads); the other instantiations -- both directions in either
-    form, 8-row tiles, default-policy loads, one workgroup per CU, and the general kernels on DMA-eligible shapes -- must
+    form, 8-row tiles, default-policy loads, one workgroup per CU, two / four rows per wave under one staged DEM tile, and the
+    general kernels on DMA-eligible shapes -- must
     stay correct too: same fp64 oracle, same tolerances, in a child process per setting."""
     import subprocess
     import sys
