@@ -21,7 +21,8 @@
 
 namespace {
 
-constexpr int HOPB = 5 * 1024;         // one row's buffer: 64 px x 64 B of head + 256 B of grad_out = 5 DMA pieces
+constexpr int HOPB_F = 4 * 1024;       // one row's buffer, forward: 64 px x 64 B of head = 4 DMA pieces
+constexpr int HOPB_B = 4 * 1024 + 256; // backward: + the row's 256 B of grad_out (a quarter piece) -- three workgroups fit a CU's 160 KB
 
 struct HdArgs {
   const float* dem;
@@ -55,11 +56,12 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {      // v_cvt_pk
 
 template <int NW, bool BWD, bool SPLIT>
 __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop_head_dma_kernel(const HdArgs A) {
+  constexpr int HOPB = BWD ? HOPB_B : HOPB_F;
   using C = DmaCfg<NW, HOPB>;
   constexpr int LH = C::LH;
   constexpr int NST = BWD ? 4 : 1;                 // vector-memory stores a valid row issues per tile
-  __shared__ __attribute__((aligned(1024))) char smem[C::SMEM];
-  __shared__ double red[NW][NRED];
+  __shared__ __attribute__((aligned(256))) char smem[C::SMEM];
+  __shared__ double red[BWD ? NW : 1][NRED];
 
   const int lane = threadIdx.x & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -299,15 +301,17 @@ template <bool BWD>
 void launch(HdArgs& A, int B, int H, int W, hipStream_t s) {
   // defaults = what measured best on MI355X; the environment is for A/B measurements
   static const int split_env = env_int("JSPSR_PROP_HEAD_SPLIT", -1);
-  static const int wgs_env = env_int("JSPSR_PROP_HEAD_WGS", 2);
+  static const int wgs_env = env_int("JSPSR_PROP_HEAD_WGS", 0);
   constexpr int NW = 4;
-  const bool split = split_env < 0 ? true : split_env != 0;      // mover / compute waves: 32.6 / 58.6 us vs 34.2 / 64.3 symmetric (profiles/r03_k1h_dma_variants.txt)
+  // forward: symmetric waves, 3 workgroups per CU (31.1 us; mover / compute waves at 2 per CU: 32.2); backward: mover /
+  // compute waves, 2 per CU (61.7 us; symmetric at 3 per CU: 63.2) -- profiles/r03_k1h_dma_variants.txt
+  const bool split = split_env < 0 ? BWD : split_env != 0;
   A.B = B; A.H = H; A.W = W;
   A.tiles_x = (W + DW - 1) / DW;
   A.tiles_y = (H + NW - 1) / NW;
   const long long n = (long long)B * A.tiles_x * A.tiles_y;
   A.ntiles = (int)n;
-  long long grid = (long long)num_cus() * (wgs_env > 0 ? wgs_env : 2);
+  long long grid = (long long)num_cus() * (wgs_env > 0 ? wgs_env : (split ? 2 : 3));
   if (grid > n) grid = n;
   if (grid > 4096) grid = 4096;
   if (split) hipLaunchKernelGGL((prop_head_dma_kernel<NW, BWD, true>), dim3((unsigned)grid), dim3(2 * NW * 64), 0, s, A);
