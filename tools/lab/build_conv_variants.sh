@@ -1,0 +1,21 @@
+#!/bin/bash
+# Lab builds (not product) of conv.hip + tools/lab/conv_movers_mfma16.patch -> jspsr_amd/lib_lab/libjspsr_conv_<name>.so,
+# loaded through JSPSR_LAB_LIB.  The patch (round 3, measured slower / too small to carry: profiles/r03_conv_patch_movers_mfma16_lab.txt)
+# adds to conv_patch_kernel<bf16,128,128>: two MOVER waves that bring the weight stages in by LDS-DMA (JSPSR_CONV_MOVERS=1/0), and
+#   movers=""                 the patched kernel as is
+#   nodma="-DCONVLAB_NODMA"   mover waves run but move nothing (WRONG results): what the weight DMA itself costs
+#   lb3="-DCONVLAB_LB=3"      the plain patch kernel held to the mover build's register budget (168 VGPRs)
+#   mfma16="-DCONVLAB_MFMA16" every 32x32x16 product replaced by two 16x16x32 ones on the same operands (WRONG results; timing only)
+set -e
+cd "$(dirname "$0")/../../jspsr_amd/csrc"
+make -s
+mkdir -p ../lib_lab
+patch -o /tmp/convlab_src.hip conv.hip ../../tools/lab/conv_movers_mfma16.patch
+cp /tmp/convlab_src.hip ./_convlab.hip; trap 'rm -f _convlab.hip' EXIT      # (includes are relative to csrc/)
+for v in "$@"; do
+  name=${v%%=*}; flags=${v#*=}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c _convlab.hip -o /tmp/convlab_$name.o
+  objs=$(ls _obj/*.o | grep -v "_obj/conv.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_lab/libjspsr_conv_$name.so /tmp/convlab_$name.o $objs
+done
+ls -la ../lib_lab
