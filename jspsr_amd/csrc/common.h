@@ -26,4 +26,28 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+// Exact n / d for every 32-bit n by one multiply-high and two shifts (Granlund & Montgomery's round-up form): the per-tile
+// index arithmetic of the tile kernels divides by launch constants, and a runtime 32-bit division costs ~30 dependent
+// instructions at the head of every workgroup.  The host makes the constants (make_fastdiv), the kernel applies them.
+struct FastDiv {
+  unsigned m, s1, s2;
+};
+inline FastDiv make_fastdiv(unsigned d) {      // d >= 1
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;                 // ceil(log2 d)
+  FastDiv f;
+  f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__host__ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned t = __umulhi(f.m, n);
+#else
+  const unsigned t = (unsigned)(((unsigned long long)f.m * n) >> 32);
+#endif
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 }  // namespace jspsr

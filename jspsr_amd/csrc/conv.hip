@@ -441,6 +441,27 @@ __global__ __launch_bounds__(NT, NBUF == 1 ? 4 : 2) void conv_igemm_kernel(const
   }
 }
 
+// Lab builds only (tools/lab/build_conv_variants.sh stamps="-DCONVLAB_STAMPS"): per-phase cycle sums of every wave of the
+// patch kernel, added into one device array that jspsr_lab_conv_stamps() reads and clears; the product build has none of it.
+#ifdef CONVLAB_STAMPS
+constexpr int CONVLAB_SLOTS = 1 << 17;           // one row of 16 per wave (rows reused modulo: later launches overwrite)
+__device__ unsigned long long convlab_stamp[CONVLAB_SLOTS * 16];
+#define CL_NOW(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#if CONVLAB_STAMPS == 2      // per-stage phases (these stamps slow the kernel several times over: read the ratios only)
+#define CL_STAMP(i) do { unsigned long long now_; CL_NOW(now_); cl_stamp[i] += now_ - cl_last; cl_last = now_; } while (0)
+#else                        // 1: four stamps in a wave's life (start, first stage ready, main loop done, end)
+#define CL_STAMP(i) do { } while (0)
+#endif
+#else
+#define CL_STAMP(i) do { } while (0)
+#endif
+#if defined(CONVLAB_STAMPS) && CONVLAB_STAMPS == 3     // 3: the prologue and the epilogue in pieces (a dozen stamps per wave)
+#define CL_STAMP3(i) do { unsigned long long now_; CL_NOW(now_); cl_stamp[i] += now_ - cl_last; cl_last = now_; } while (0)
+#else
+#define CL_STAMP3(i) do { } while (0)
+#endif
+
 __host__ __device__ constexpr int patch_it(int BM, int NTH) { return ((BM / 16 + 2) * 18 * NCH + NTH - 1) / NTH; }
 
 // ---------------------------------------------------------------------------------------------
@@ -472,15 +493,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
   char* Ps = smem;                          // [MAXPIX][ROWB]   input patch of the current channel chunk
   char* Bs = smem + MAXPIX * ROWB;          // [2][BN][ROWB]    weight tile of the current / next tap
 
+#ifdef CONVLAB_STAMPS
+  unsigned long long cl_entry, cl_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cl_last = 0, cl_first = 0;
+  CL_NOW(cl_entry);
+  cl_last = cl_entry;
+#endif
   const int tid = threadIdx.x;
   const int ntn = (g.Cout + BN - 1) / BN;
   const int ttx = (g.MW + TLW - 1) / TLW, tty = (g.MH + TLH - 1) / TLH;
   const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int n0 = (t % ntn) * BN;
-  const int mt = t / ntn;
-  const int txi = mt % ttx, tyi = (mt / ttx) % tty, bimg = mt / (ttx * tty);
+  // (divisions by launch constants: common.h FastDiv -- five runtime divisions at the head of every workgroup were most
+  // of the 3.7 k cycles a wave spent before its first load, profiles/r03_conv_patch_wave_life.txt)
+  const int mt = (int)fastdiv((unsigned)t, g.fd_ntn);
+  const int n0 = (t - mt * ntn) * BN;
+  const int mrow = (int)fastdiv((unsigned)mt, g.fd_ttx), txi = mt - mrow * ttx;
+  const int bimg = (int)fastdiv((unsigned)mrow, g.fd_tty), tyi = mrow - bimg * tty;
   const int ty0 = tyi * TLH, tx0 = txi * TLW;
 
+  CL_STAMP3(4);                  // tile coordinates (first kernel arguments read)
   const int PW = TLW + g.ntx - 1, PH = TLH + g.nty - 1, npix = PW * PH;
   const int pix_bytes = g.in_cstride * (int)sizeof(T);
   // patch origin in the gathered raster (reversed walk: the patch starts nty-1 / ntx-1 pixels earlier)
@@ -497,8 +527,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
   unsigned poff[P_IT];       // global byte offset of the pixel (+ chunk) from the patch origin, OOB if padding
   int plds[P_IT];            // LDS byte offset, -1 if this slot is beyond the patch
   {
-    int pp = tid >> 3;
-    int py = pp / PW, px = pp - py * PW;
+    // patch pixel pp = py * PW + px, walked in steps of RPI: PW is 16, 17 or 18 (1..3 taps across), so the row / column
+    // split needs no division -- at most RPI / 16 conditional subtractions at the start, one per step after
+    const int qd = g.ntx == 1 ? RPI / 16 : g.ntx == 2 ? RPI / 17 : RPI / 18, rd = RPI - qd * PW;
+    int pp = tid >> 3, py = 0, px = pp;
+#pragma unroll
+    for (int k = 0; k < RPI / 16; ++k)
+      if (px >= PW) { px -= PW; ++py; }
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
       const bool inpatch = pp < npix;
@@ -507,8 +542,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
       poff[i] = ok ? (unsigned)((py * g.IW + px) * pix_bytes) + ch * 16u : OOB;
       plds[i] = inpatch ? pp * ROWB + ch * 16 : -1;
       pp += RPI;
-      px += RPI;
-      while (px >= PW) { px -= PW; ++py; }
+      py += qd;
+      px += rd;
+      if (px >= PW) { px -= PW; ++py; }
     }
   }
   const int r0 = tid >> 3;
@@ -644,24 +680,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
     load_b(CUR);                                               // weights of stage s+2
     const bool first_tap = (cty == 0 && ctx == 0), more = cchunk + 1 < nchunks;
     if (first_tap && more) load_patch(cchunk + 1);             // next chunk's patch: lands during this chunk's taps
+    CL_STAMP(0);
     compute(CUR);
+    CL_STAMP(1);
     const bool last_tap = (cty == g.nty - 1 && ctx == g.ntx - 1);
     if (last_tap && more) {
       __syncthreads();                                         // everyone is done with this chunk's patch
       store_patch();
     }
+    CL_STAMP(2);
     store_b(NXT, NXT);
+    CL_STAMP(3);
     __syncthreads();
+    CL_STAMP(4);
     if (++ctx == g.ntx) { ctx = 0; if (++cty == g.nty) { cty = 0; ++cchunk; } }
   };
+  CL_STAMP3(5);                  // the tile's plan
   if (KT > 0) {
     load_patch(0);
     load_b(S0{});
     load_b(S1{});
+    CL_STAMP3(6);                // loads issued
     store_patch();
     store_b(S0{}, S0{});
   }
+  CL_STAMP3(7);                  // first patch + weights waited for and stored
   __syncthreads();
+#ifdef CONVLAB_STAMPS
+  CL_NOW(cl_last);
+  cl_first = cl_last;
+#endif
+#ifdef CONVLAB_PRIO     // lab: the workgroups of every other dispatch round at raised priority (see tools/lab/build_conv_variants.sh)
+  if ((blockIdx.x >> CONVLAB_PRIO) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
   int kt = 0;
   for (; kt + 1 < KT; kt += 2) {
     step(S0{}, S1{});
@@ -669,6 +720,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
   }
   if (kt < KT) step(S0{}, S1{});
 
+#ifdef CONVLAB_STAMPS
+  unsigned long long cl_loop;
+  CL_NOW(cl_loop);
+  cl_last = cl_loop;
+#endif
   // ---- epilogue (as above): transpose through LDS, 16-byte stores ----------------------------
   auto out_pixel = [&](int row) -> long long {
     const int y = ty0 + (row >> 4), x = tx0 + ((row + rot * (row >> 4)) & (TLW - 1));
@@ -707,23 +763,45 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
                                      ((g.add_cstride * (int)sizeof(T)) % 16 == 0) && ((n0 * (int)sizeof(T)) % 16 == 0)));
   if (vec_ok) {
     constexpr int CPRO = BN * (int)sizeof(T) / 16;       // 16-byte chunks per output row
-    constexpr int O_IT = BM * CPRO / NTH, A_PRE = O_IT <= 8 ? O_IT : 1;
-    static_assert(BM * CPRO % NTH == 0, "epilogue rows");
-    // the addend's 16-byte pieces are requested up front: they fly during the accumulator -> LDS transpose and
-    // the barrier instead of one exposed memory latency per piece in the copy loop below
-    uint4 areg[A_PRE];
-    const bool add_pre = g.addend && O_IT <= 8;
-    if (add_pre) {
+    constexpr int O_IT = BM * CPRO / NTH, OB = O_IT <= 8 ? O_IT : 8;
+    static_assert(BM * CPRO % NTH == 0 && O_IT % OB == 0, "epilogue rows");
+    // Where this thread's pieces of the tile go, and the addend's pieces, are worked out and requested BEFORE the
+    // accumulator -> LDS transpose (the first OB = 8 of them when fp32 tiles have 16): the 64-bit pixel arithmetic and
+    // the addend's memory latency then sit beside the transpose and the barrier, and the copy loop behind the barrier is
+    // OB LDS reads in a row followed by OB stores (it was read - address - store per piece: 3.5 k cycles per wave,
+    // profiles/r03_conv_patch_wave_life.txt).
+    long long ooff[OB];        // byte offset from obase, -1: nothing to store (outside the written grid / beyond Cout)
+    uint4 areg[OB];
+    // Beside a partner wave that keeps the matrix pipe busy a vector instruction of this wave costs ~10 cycles, so the
+    // per-piece arithmetic is kept short: the tile's origin on the written grid and its byte offset are wave-uniform
+    // (scalar unit, 64-bit), a piece adds a 32-bit pixel delta by one v_mad_u64_u32, and the bounds tests are skipped
+    // for tiles that lie wholly inside the grid.
+    const int oy_t = ty0 * g.oy_mul + g.oy_add, ox_t = tx0 * g.ox_mul + g.ox_add, ystep = g.oy_mul * g.OW;
+    const long long pix_t = ((long long)bimg * g.OH + oy_t) * g.OW + ox_t;
+    const unsigned ocs = (unsigned)g.out_cstride * (unsigned)sizeof(T), acs = (unsigned)g.add_cstride * (unsigned)sizeof(T);
+    const long long obase_t = pix_t * ocs, abase_t = pix_t * acs + n0 * (long long)sizeof(T);
+    const bool inside = ty0 + TLH <= g.MH && tx0 + TLW <= g.MW && oy_t + (TLH - 1) * g.oy_mul < g.OH &&
+                        ox_t + (TLW - 1) * g.ox_mul < g.OW && n0 + BN <= g.Cout;
+    auto plan_pieces = [&](int j0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < A_PRE; ++j) {
-        const int i = tid + j * NTH, row = i / CPRO, c16 = i % CPRO;
-        const long long opix = out_pixel(row);
-        areg[j] = make_uint4(0, 0, 0, 0);
-        if (opix >= 0 && n0 + c16 * EPC < g.Cout)
-          areg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
-                                                    (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16);
+      for (int j = 0; j < OB; ++j) {
+        const int i = tid + (j0 + j) * NTH, row = i / CPRO, c16 = i % CPRO;
+        const int dy = row >> 4, dx = (row + rot * dy) & (TLW - 1);
+        const unsigned dpix = (unsigned)(dy * ystep + dx * g.ox_mul);        // < 2^31 (checked by the launcher)
+        bool ok = true;
+        if (!inside)
+          ok = ty0 + dy < g.MH && tx0 + dx < g.MW && oy_t + dy * g.oy_mul < g.OH && ox_t + dx * g.ox_mul < g.OW &&
+               n0 + c16 * EPC < g.Cout;
+        ooff[j] = ok ? obase_t + (long long)((unsigned long long)dpix * ocs) + c16 * 16 : -1;
+        if (g.addend) {
+          areg[j] = make_uint4(0, 0, 0, 0);
+          if (ok)
+            areg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) + abase_t +
+                                                      (long long)((unsigned long long)dpix * acs) + c16 * 16);
+        }
       }
-    }
+    };
+    plan_pieces(0);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -736,21 +814,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
           *reinterpret_cast<T*>(Os + row * OPITCH + (wn * WTN + ni * 32 + lr) * (int)sizeof(T)) = (T)v;
         }
       }
+    CL_STAMP3(0);                // accumulators -> LDS
     __syncthreads();
+    CL_STAMP3(1);                // barrier
     char* const obase = reinterpret_cast<char*>(out + g.out_coff + n0);
 #pragma unroll
-    for (int j = 0; j < O_IT; ++j) {
-      const int i = tid + j * NTH, row = i / CPRO, c16 = i % CPRO;
-      const long long opix = out_pixel(row);
-      if (opix < 0 || n0 + c16 * EPC >= g.Cout) continue;
-      uint4 v = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
-      if (add_pre)
-        v = add_packed<T>(v, areg[j < A_PRE ? j : 0]);
-      else if (g.addend)
-        v = add_packed<T>(v, *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) +
-                                                              (opix * g.add_cstride + n0) * (long long)sizeof(T) + c16 * 16));
-      if (relu_last) v = relu_packed<T>(v);
-      *reinterpret_cast<uint4*>(obase + opix * g.out_cstride * (long long)sizeof(T) + c16 * 16) = v;
+    for (int j0 = 0; j0 < O_IT; j0 += OB) {
+      if (j0) plan_pieces(j0);
+      uint4 ov[OB];
+#pragma unroll
+      for (int j = 0; j < OB; ++j) {
+        const int i = tid + (j0 + j) * NTH, row = i / CPRO, c16 = i % CPRO;
+        ov[j] = *reinterpret_cast<const uint4*>(Os + row * OPITCH + c16 * 16);
+      }
+      CL_STAMP3(2);              // tile pieces read back from LDS
+#pragma unroll
+      for (int j = 0; j < OB; ++j) {
+        if (ooff[j] < 0) continue;
+        uint4 v = ov[j];
+        if (g.addend) v = add_packed<T>(v, areg[j]);
+        if (relu_last) v = relu_packed<T>(v);
+        *reinterpret_cast<uint4*>(obase + ooff[j]) = v;
+      }
     }
   } else {
 #pragma unroll
@@ -772,15 +857,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
         }
       }
   }
+#ifdef CONVLAB_STAMPS
+  if ((tid & 63) == 0) {
+    unsigned long long end_;
+    CL_NOW(end_);
+    unsigned long long* o = convlab_stamp + (size_t)((blockIdx.x * (NTH / 64) + (tid >> 6)) % CONVLAB_SLOTS) * 16;
+    for (int i = 0; i < 4; ++i) o[i] = cl_stamp[i] + (i == 3 ? cl_stamp[4] : 0);   // (3: weight store + stage barrier; level 3: 0, 1 = epilogue pieces)
+    o[4] = cl_first - cl_entry;     // entry .. first stage staged and the barrier behind it
+    o[5] = cl_loop - cl_first;      // main loop
+    o[6] = end_ - cl_loop;          // epilogue
+    for (int i = 5; i < 8; ++i) o[3 + i] = cl_stamp[i];      // level 3: 8 plan, 9 loads issued, 10 wait + store
+    o[11] = cl_stamp[4];                                     // level 3: head of the plan (tile coordinates)
+    o[7] = (unsigned long long)KT;  // stages
+  }
+#endif
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_patch(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
   constexpr int NTH = 64 * WGM * WGN, TLW = 16, TLH = BM / TLW, MAXPIX = patch_it(BM, NTH) * NTH / NCH;
   const long long nblk = (long long)g.B * ((g.MH + TLH - 1) / TLH) * ((g.MW + TLW - 1) / TLW) * ((g.Cout + BN - 1) / BN);
-  if (nblk > 0x7fffffffLL) return fail(JSPSR_EINVAL, "conv: grid too large");
+  if (nblk > 0x7fffffffLL || (long long)TLH * g.oy_mul * g.OW + (long long)TLW * g.ox_mul > 0x7fffffffLL)
+    return fail(JSPSR_EINVAL, "conv: grid too large");
   const size_t lds_stage = (size_t)MAXPIX * ROWB + 2 * BN * ROWB, lds_out = (size_t)BM * (BN * sizeof(T) + 16);
   const size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
+  ConvGeom gk = g;
+  gk.fd_ntn = make_fastdiv((unsigned)((g.Cout + BN - 1) / BN));
+  gk.fd_ttx = make_fastdiv((unsigned)((g.MW + TLW - 1) / TLW));
+  gk.fd_tty = make_fastdiv((unsigned)((g.MH + TLH - 1) / TLH));
   auto kern = conv_patch_kernel<T, BM, BN, WGM, WGN>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -788,7 +892,7 @@ int launch_patch(const void* in, const void* wgt, const float* bias, void* out, 
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTH), lds, s, static_cast<const T*>(in), static_cast<const T*>(wgt),
-                     bias, static_cast<T*>(out), stats, g);
+                     bias, static_cast<T*>(out), stats, gk);
   return check_launch(BM == 256 ? (BN == 64 ? "conv_patch_16x16" : "conv_patch_16x16x128") : "conv_patch");
 }
 
@@ -1024,3 +1128,15 @@ extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack
     }
   return JSPSR_OK;
 }
+
+#ifdef CONVLAB_STAMPS
+extern "C" int jspsr_lab_conv_stamps(unsigned long long* out16, int reset) {      // sums over the wave rows written so far
+  static unsigned long long host[CONVLAB_SLOTS * 16];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(convlab_stamp), sizeof(host)) != hipSuccess) return 1;
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+  for (int r = 0; r < CONVLAB_SLOTS; ++r)
+    if (host[r * 16 + 7]) { for (int i = 0; i < 16; ++i) out16[i] += host[r * 16 + i]; }
+  if (reset) { for (size_t i = 0; i < sizeof(host) / 8; ++i) host[i] = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(convlab_stamp), host, sizeof(host)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif

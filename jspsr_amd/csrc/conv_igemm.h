@@ -49,6 +49,7 @@ struct ConvGeom {
   const float* scale;     // optional per-output-channel factor (inference: BatchNorm folded into the epilogue)
   const float* in_affine; // optional [2][Cin] (scale | shift): the gathered tensor is read as [relu](x * scale + shift),
   int in_relu;            // applied while the patch is staged (patch kernel only); zero padding stays zero
+  FastDiv fd_ntn, fd_ttx, fd_tty;   // patch kernel: division by its N-tile / tile-column / tile-row counts (set by its launcher)
 };
 
 // K2r (conv64.hip): 3x3 64->64 unit-stride bf16 conv / data gradient, weights resident in registers

@@ -89,3 +89,49 @@ def test_warmup_step_lr_matches_the_reference_composition():
                 ropt.step()
                 ref.step()
                 mine.step()
+
+
+def test_fastdiv_is_exact(tmp_path):
+    """csrc/common.h FastDiv (the tile kernels' division by launch constants) against `/` on the host: every divisor up
+    to 4096 and a spread of large ones, dividends at the quotient boundaries and across the 32-bit range."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = tmp_path / "fd.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdint>
+#define __host__
+#define __device__
+#define __forceinline__ inline
+struct FastDiv { unsigned m, s1, s2; };
+#define JSPSR_FASTDIV_ONLY
+''' + _extract_fastdiv(os.path.join(here, "..", "jspsr_amd", "csrc", "common.h")) + r'''
+int main() {
+  unsigned long long bad = 0, n_checked = 0;
+  auto check = [&](unsigned d) {
+    const FastDiv f = make_fastdiv(d);
+    const unsigned ns[] = {0u, 1u, d - 1, d, d + 1, 2 * d - 1, 2 * d, 12345u * d, 12345u * d - 1, 0x7fffffffu, 0x80000000u, 0xfffffffeu, 0xffffffffu,
+                           0xffffffffu / d * d, 0xffffffffu / d * d - 1};
+    for (unsigned n : ns) { ++n_checked; if (fastdiv(n, f) != n / d) ++bad; }
+    for (unsigned k = 0; k < 64; ++k) { const unsigned n = k * 0x04000001u + k * k * 977u; ++n_checked; if (fastdiv(n, f) != n / d) ++bad; }
+  };
+  for (unsigned d = 1; d <= 4096; ++d) check(d);
+  for (unsigned d = 4097; d < 0xfff00000u; d += 104729u) check(d);
+  check(0x7fffffffu); check(0x80000000u); check(0x80000001u); check(0xffffffffu);
+  std::printf("%llu %llu\n", n_checked, bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / "fd"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) > 300000 and int(out[1]) == 0
+
+
+def _extract_fastdiv(path):
+    """the two functions of common.h that implement FastDiv, as text (compiled by g++ beside a reference division)"""
+    s = open(path).read()
+    a = s.index("inline FastDiv make_fastdiv")
+    b = s.index("}  // namespace jspsr", a)
+    body = s[a:b]
+    return body.replace("__umulhi(f.m, n)", "0")      # (the device branch is preprocessed away; keep g++ happy anyway)
