@@ -9,12 +9,13 @@
 //   * data gradient of a conv and ConvTranspose2d forward         [autograd of the above; basics.py:69-77]
 //     -- "transposed" tap walk (input row = base - tap), one launch per stride phase so that no
 //        MFMA work is spent on structurally-zero taps.
-// LDS image: rows of 128 B (+16 B pad -> conflict-free ds_read_b128), 16-byte chunks; lane
-// (r = l & 31, h = l >> 5) of a 32-row MFMA tile reads chunk 2s+h of row r at sub-step s.
-//   fp32:  a chunk is 4 k-values  -> 4 x v_mfma_f32_32x32x2_f32   (exact fp32 FMA chain)
-//   bf16:  a chunk is 8 k-values  -> 1 x v_mfma_f32_32x32x16_bf16 (fp32 accumulate)
-// (the k order inside a 32-byte pair is permuted identically for A and B, which is all a
-// dot product needs).
+// LDS image: rows of 128 B of K (+ pad), 16-byte chunks; how a lane picks its chunk depends on the product (conv.hip `Mma`):
+//   fp32:  144-byte rows, a chunk is 4 k-values; lane (r = l & 31, h = l >> 5) of a 32-row block reads chunk 2s + h of
+//          row r at sub-step s -> 4 x v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)
+//   bf16:  160-byte rows, a chunk is 8 k-values; lane (r = l & 15, q = l >> 4) of a 16-row block reads chunk 4s + q of
+//          row r -> 1 x v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  Round 3 (was 32x32x16): same cycles and LDS
+//          traffic per flop, but the chip holds a higher clock on the 16x16x32 shape.
+// (the k order inside a sub-step is permuted identically for A and B, which is all a dot product needs).
 #pragma once
 #include "common.h"
 
