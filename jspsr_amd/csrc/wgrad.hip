@@ -39,6 +39,26 @@ template <typename T> struct WT;
 template <> struct WT<float> { static constexpr int EPC = 4, BKM = 32; };
 template <> struct WT<__bf16> { static constexpr int EPC = 8, BKM = 64; };
 
+// bf16 product of the weight-gradient kernels.  -DWGRADLAB_MFMA16 (kernel-lab timing build, WRONG results): the same flops and
+// operand reads as two 16x16x32 products, to price the conversion the conv kernels got in round 3 (conv.hip `Mma`).
+#ifdef WGRADLAB_MFMA16
+#define WG_NM 6
+#else
+#define WG_NM 3      // MFMAs per (k-block, tap row) group of the patch kernel's pinned schedule
+#endif
+__device__ __forceinline__ f32x16 wg_mma(const bf16x8& a, const bf16x8& b, f32x16 acc) {
+#ifndef WGRADLAB_MFMA16
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#else
+  f32x4 c0 = {acc[0], acc[1], acc[2], acc[3]}, c1 = {acc[4], acc[5], acc[6], acc[7]};
+  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+  acc[0] = c0[0]; acc[1] = c0[1]; acc[2] = c0[2]; acc[3] = c0[3];
+  acc[4] = c1[0]; acc[5] = c1[1]; acc[6] = c1[2]; acc[7] = c1[3];
+  return acc;
+#endif
+}
+
 __host__ __device__ constexpr int pitch_bytes(int row_bytes) {
   return row_bytes + ((row_bytes % 128 == 0) ? 64 : 0);
 }
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const T* __restrict__ G, c
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = wg_mma(a[mi], b[ni], acc[mi][ni]);
       }
     }
   };
@@ -444,7 +464,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
         const int kb = grp / 3, ky = grp % 3;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
-          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kb & 1], bfr[grp & 1][kx], acc[ky * 3 + kx], 0, 0, 0);
+          acc[ky * 3 + kx] = wg_mma(a[kb & 1], bfr[grp & 1][kx], acc[ky * 3 + kx]);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_patch_kernel(const T* __restrict_
           if ((grp + 1) % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
           else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, WG_NM, 0);
       }
     }
   };
