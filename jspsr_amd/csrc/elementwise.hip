@@ -27,10 +27,12 @@ template <> struct V<__bf16> { static constexpr int N = 8; };
 template <typename T, int N>
 struct Pack { T v[N]; };
 
+// 16 bytes of T (4 fp32 / 8 bf16 channels) in two halves -- the raw bytes now, the fp32 values later -- so that the pixel
+// walks below can keep several pixels in flight
 template <typename T>
-__device__ __forceinline__ void load_vec(const T* p, float (&f)[V<T>::N]) {
-  constexpr int N = V<T>::N;
-  const uint4 raw = *reinterpret_cast<const uint4*>(p);
+__device__ __forceinline__ uint4 load_raw(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+template <typename T>
+__device__ __forceinline__ void unpack(const uint4& raw, float (&f)[V<T>::N]) {
   if constexpr (sizeof(T) == 4) {
     f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y); f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
   } else {
@@ -41,7 +43,6 @@ __device__ __forceinline__ void load_vec(const T* p, float (&f)[V<T>::N]) {
       f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
   }
-  (void)N;
 }
 
 __device__ __forceinline__ unsigned bf16_bits(float x) {  // round-to-nearest-even, NaN preserved
@@ -94,45 +95,6 @@ __device__ __forceinline__ LaneMap lane_map(const RedGeom& g) {
   return m;
 }
 
-// Generic per-channel reduction: F supplies K accumulators per channel.
-// partial layout: [seg][chunk][K][C]
-template <typename T, int K, typename F>
-__device__ __forceinline__ void reduce_pixels(const RedGeom& g, float* __restrict__ partial, F&& body) {
-  constexpr int N = V<T>::N;
-  __shared__ float red[TY][K][TX * N];
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const LaneMap lm = lane_map<N>(g);
-  const int c = lm.c;
-  const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
-  float acc[K][N];
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-#pragma unroll
-    for (int i = 0; i < N; ++i) acc[k][i] = 0.f;
-  const long long p0 = chunk * g.chunk_pix;
-  const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
-  if (c < g.C)
-    for (long long p = p0 + ty * g.pl + lm.sub; p < p1; p += TY * g.pl) body((long long)seg * g.npix + p, c, acc);
-#pragma unroll
-  for (int k = 0; k < K; ++k)
-#pragma unroll
-    for (int i = 0; i < N; ++i) red[ty][k][tx * N + i] = acc[k][i];
-  __syncthreads();
-  if (ty == 0 && lm.sub == 0 && c < g.C) {
-    float* dst = partial + ((size_t)blockIdx.x * K) * g.C + c;
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        float s = 0.f;
-        for (int j = 0; j < g.pl; ++j)
-#pragma unroll
-          for (int y = 0; y < TY; ++y) s += red[y][k][(tx + j * g.lpp) * N + i];
-        dst[(size_t)k * g.C + i] = s;
-      }
-  }
-}
-
 RedGeom make_red(long long npix, int nseg, int C, int vec) {
   RedGeom g;
   g.npix = npix; g.nseg = nseg; g.C = C;
@@ -152,10 +114,67 @@ RedGeom make_red(long long npix, int nseg, int C, int vec) {
 }
 dim3 red_grid(const RedGeom& g, int vec) { return dim3(g.nseg * g.chunks, (g.C / vec + TX - 1) / TX); }
 
-// Same geometry without a reduction: a lane owns one 16-byte channel group (per-channel
-// parameters are loaded into registers once) and walks the pixels of its chunk.
-template <typename T, typename F>
-__device__ __forceinline__ void for_pixels(const RedGeom& g, F&& body) {
+// The two pixel walks of this file: a per-channel reduction (K accumulators per channel, partial layout
+// [seg][chunk][K][C]) and the same geometry without one (a lane owns one 16-byte channel group, per-channel parameters in
+// registers, and walks the pixels of its chunk) -- both with FOUR pixels in flight per lane since round 3 (one before).
+// `load(pix, c, raw)` fetches the NTEN 16-byte pieces
+// of one pixel, `use(pix, c, raw[, acc])` consumes them; a trip issues the loads of four pixels back to back and only then
+// works through them, in pixel order (so sums keep their order and their bits).  One pixel per trip left 2-3 x 16 bytes
+// per lane in flight -- about 32 KB per CU at 16 waves, under half of what hides an HBM miss; the BatchNorm backward
+// pair ran at 4.5 TB/s effective where a plain stream reaches 5.5 (tools/bench_bn.py).
+constexpr int PIX_FLY = 4;
+template <typename T, int K, int NTEN, typename L, typename F>
+__device__ __forceinline__ void reduce_pixels_mlp(const RedGeom& g, float* __restrict__ partial, L&& load, F&& use) {
+  constexpr int N = V<T>::N;
+  __shared__ float red[TY][K][TX * N];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const LaneMap lm = lane_map<N>(g);
+  const int c = lm.c;
+  const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
+  float acc[K][N];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[k][i] = 0.f;
+  const long long p0 = chunk * g.chunk_pix;
+  const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
+  if (c < g.C) {
+    const long long step = TY * g.pl, base = (long long)seg * g.npix;
+    long long p = p0 + ty * g.pl + lm.sub;
+    for (; p + (PIX_FLY - 1) * step < p1; p += PIX_FLY * step) {
+      uint4 raw[PIX_FLY][NTEN];
+#pragma unroll
+      for (int u = 0; u < PIX_FLY; ++u) load(base + p + u * step, c, raw[u]);
+#pragma unroll
+      for (int u = 0; u < PIX_FLY; ++u) use(base + p + u * step, c, raw[u], acc);
+    }
+    for (; p < p1; p += step) {
+      uint4 raw[NTEN];
+      load(base + p, c, raw);
+      use(base + p, c, raw, acc);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[ty][k][tx * N + i] = acc[k][i];
+  __syncthreads();
+  if (ty == 0 && lm.sub == 0 && c < g.C) {
+    float* dst = partial + ((size_t)blockIdx.x * K) * g.C + c;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        float s = 0.f;
+        for (int j = 0; j < g.pl; ++j)
+#pragma unroll
+          for (int y = 0; y < TY; ++y) s += red[y][k][(tx + j * g.lpp) * N + i];
+        dst[(size_t)k * g.C + i] = s;
+      }
+  }
+}
+template <typename T, int NTEN, typename L, typename F>
+__device__ __forceinline__ void for_pixels_mlp(const RedGeom& g, L&& load, F&& use) {
   constexpr int N = V<T>::N;
   const LaneMap lm = lane_map<N>(g);
   const int c = lm.c;
@@ -163,7 +182,20 @@ __device__ __forceinline__ void for_pixels(const RedGeom& g, F&& body) {
   const int seg = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
   const long long p0 = chunk * g.chunk_pix;
   const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
-  for (long long p = p0 + threadIdx.y * g.pl + lm.sub; p < p1; p += TY * g.pl) body(seg, p, (long long)seg * g.npix + p, c);
+  const long long step = TY * g.pl, base = (long long)seg * g.npix;
+  long long p = p0 + threadIdx.y * g.pl + lm.sub;
+  for (; p + (PIX_FLY - 1) * step < p1; p += PIX_FLY * step) {
+    uint4 raw[PIX_FLY][NTEN];
+#pragma unroll
+    for (int u = 0; u < PIX_FLY; ++u) load(base + p + u * step, c, raw[u]);
+#pragma unroll
+    for (int u = 0; u < PIX_FLY; ++u) use(p + u * step, base + p + u * step, c, raw[u]);
+  }
+  for (; p < p1; p += step) {
+    uint4 raw[NTEN];
+    load(base + p, c, raw);
+    use(p, base + p, c, raw);
+  }
 }
 
 template <int N>
@@ -218,12 +250,14 @@ template <typename T>
 __global__ __launch_bounds__(TX * TY) void bn_stats_kernel(const T* __restrict__ x, int cs, int coff, RedGeom g,
                                                           float* __restrict__ partial) {
   constexpr int N = V<T>::N;
-  reduce_pixels<T, 2>(g, partial, [&](long long pix, int c, float (&acc)[2][N]) {
-    float f[N];
-    load_vec<T>(x + (size_t)pix * cs + coff + c, f);
+  reduce_pixels_mlp<T, 2, 1>(
+      g, partial, [&](long long pix, int c, uint4 (&raw)[1]) { raw[0] = load_raw<T>(x + (size_t)pix * cs + coff + c); },
+      [&](long long, int, const uint4 (&raw)[1], float (&acc)[2][N]) {
+        float f[N];
+        unpack<T>(raw[0], f);
 #pragma unroll
-    for (int i = 0; i < N; ++i) { acc[0][i] += f[i]; acc[1][i] += f[i] * f[i]; }
-  });
+        for (int i = 0; i < N; ++i) { acc[0][i] += f[i]; acc[1][i] += f[i] * f[i]; }
+      });
 }
 
 // out[r][j] = sum of in[i][j] over rows i == r (mod nout): folds many partial rows into nout rows,
@@ -295,7 +329,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 }
 
 // y = [relu]( (x*scale + shift) * res_scale + res )
-template <typename T>
+template <typename T, bool RES>
 __global__ __launch_bounds__(TX * TY) void bn_apply_kernel(const T* __restrict__ x, int x_cs, int x_coff,
                                                           const T* __restrict__ res, int r_cs, int r_coff,
                                                           T* __restrict__ y, int y_cs, int y_coff,
@@ -308,55 +342,69 @@ __global__ __launch_bounds__(TX * TY) void bn_apply_kernel(const T* __restrict__
   // raff: the residual operand is itself the pre-normalisation output of a BatchNorm (the 1x1 projection of a
   // BasicBlock's shortcut): its per-channel (scale | shift) is applied here, in fp32, instead of in a pass of its own
   if (raff && c0 < g.C) { load_param<N>(raff + c0, rsc); load_param<N>(raff + g.C + c0, rsh); }
-  for_pixels<T>(g, [&](int, long long, long long pix, int c) {
-    float f[N], r[N];
-    load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, f);
-    if (res) load_vec<T>(res + (size_t)pix * r_cs + r_coff + c, r);
+  constexpr int NTEN = RES ? 2 : 1;
+  for_pixels_mlp<T, NTEN>(
+      g,
+      [&](long long pix, int c, uint4 (&raw)[NTEN]) {
+        raw[0] = load_raw<T>(x + (size_t)pix * x_cs + x_coff + c);
+        if constexpr (RES) raw[1] = load_raw<T>(res + (size_t)pix * r_cs + r_coff + c);
+      },
+      [&](long long, long long pix, int c, const uint4 (&raw)[NTEN]) {
+        float f[N], r[N];
+        unpack<T>(raw[0], f);
+        if constexpr (RES) unpack<T>(raw[1], r);
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      float v = f[k] * sc[k] + sh[k];
-      if (res) v = v * res_scale + (raff ? r[k] * rsc[k] + rsh[k] : r[k]);
-      if (relu) v = fmaxf(v, 0.f);
-      f[k] = v;
-    }
-    store_vec<T>(y + (size_t)pix * y_cs + y_coff + c, f);
-  });
+        for (int k = 0; k < N; ++k) {
+          float v = f[k] * sc[k] + sh[k];
+          if (RES) v = v * res_scale + (raff ? r[k] * rsc[k] + rsh[k] : r[k]);
+          if (relu) v = fmaxf(v, 0.f);
+          f[k] = v;
+        }
+        store_vec<T>(y + (size_t)pix * y_cs + y_coff + c, f);
+      });
 }
 
 // ---------------------------------------------------------------- BatchNorm backward
 // dz = dy * (y > 0 if relu);  partial sums of dz and dz * xhat
-template <typename T>
+// RELU (compile time, so that the pixel loop has no branch between its loads): 0 none; 1 mask from the saved output y;
+// 2 (no residual) mask recomputed from x, [gamma*xhat + beta > 0], which saves reading y.
+template <typename T, int RELU>
 __global__ __launch_bounds__(TX * TY) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
                                                                const T* __restrict__ y, int y_cs, int y_coff,
                                                                const T* __restrict__ x, int x_cs, int x_coff,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, int relu, RedGeom g,
+                                                               const float* __restrict__ beta, RedGeom g,
                                                                float* __restrict__ partial) {
-  constexpr int N = V<T>::N;
-  // relu == 1: mask from the saved output y;  relu == 2 (no residual): mask recomputed from x,
-  // [gamma*xhat + beta > 0], which saves reading y.  Per-channel parameters live in registers.
-  float mu[N], is[N], ga[N], be[N];
+  constexpr int N = V<T>::N, NTEN = RELU == 1 ? 3 : 2;
+  float mu[N], is[N], ga[N], be[N];       // per-channel parameters live in registers
   const int c0 = lane_map<N>(g).c;
   if (c0 < g.C) {
     load_param<N>(mean + c0, mu); load_param<N>(invstd + c0, is);
-    if (relu == 2) { load_param<N>(gamma + c0, ga); load_param<N>(beta + c0, be); }
+    if (RELU == 2) { load_param<N>(gamma + c0, ga); load_param<N>(beta + c0, be); }
   }
-  reduce_pixels<T, 2>(g, partial, [&](long long pix, int c, float (&acc)[2][N]) {
-    float d[N], xv[N], yv[N];
-    load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
-    load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, xv);
-    if (relu == 1) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
+  reduce_pixels_mlp<T, 2, NTEN>(
+      g, partial,
+      [&](long long pix, int c, uint4 (&raw)[NTEN]) {
+        raw[0] = load_raw<T>(dy + (size_t)pix * dy_cs + dy_coff + c);
+        raw[1] = load_raw<T>(x + (size_t)pix * x_cs + x_coff + c);
+        if constexpr (RELU == 1) raw[2] = load_raw<T>(y + (size_t)pix * y_cs + y_coff + c);
+      },
+      [&](long long, int, const uint4 (&raw)[NTEN], float (&acc)[2][N]) {
+        float d[N], xv[N], yv[N];
+        unpack<T>(raw[0], d);
+        unpack<T>(raw[1], xv);
+        if constexpr (RELU == 1) unpack<T>(raw[2], yv);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const float xhat = (xv[i] - mu[i]) * is[i];
-      const bool off = relu == 1 ? !(yv[i] > 0.f) : (relu == 2 ? !(ga[i] * xhat + be[i] > 0.f) : false);
-      const float dz = off ? 0.f : d[i];
-      acc[0][i] += dz;
-      acc[1][i] += dz * xhat;
-    }
-  });
+        for (int i = 0; i < N; ++i) {
+          const float xhat = (xv[i] - mu[i]) * is[i];
+          const bool off = RELU == 1 ? !(yv[i] > 0.f) : (RELU == 2 ? !(ga[i] * xhat + be[i] > 0.f) : false);
+          const float dz = off ? 0.f : d[i];
+          acc[0][i] += dz;
+          acc[1][i] += dz * xhat;
+        }
+      });
 }
 
 // dbeta = sum dz ; dgamma = sum dz*xhat ; coefficients for the apply pass
@@ -378,59 +426,74 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int ro
   coef[2 * C + c] = training ? (float)(sx / (double)count) : 0.f;   // b = mean(dz * xhat)
 }
 
-template <typename T>
+template <typename T, int RELU>
 __global__ __launch_bounds__(TX * TY) void bn_bwd_apply_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
                                                               const T* __restrict__ y, int y_cs, int y_coff,
                                                               const T* __restrict__ x, int x_cs, int x_coff,
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              const float* __restrict__ coef, int relu,
+                                                              const float* __restrict__ coef,
                                                               T* __restrict__ dx, T* __restrict__ dres, RedGeom g) {
-  constexpr int N = V<T>::N;
+  constexpr int N = V<T>::N, NTEN = RELU == 1 ? 3 : 2;
   const int C = g.C;
   float mu[N], is[N], k0[N], ka[N], kb[N], ga[N], be[N];
   const int c0 = lane_map<N>(g).c;
   if (c0 < C) {
     load_param<N>(mean + c0, mu); load_param<N>(invstd + c0, is);
     load_param<N>(coef + c0, k0); load_param<N>(coef + C + c0, ka); load_param<N>(coef + 2 * C + c0, kb);
-    if (relu == 2) { load_param<N>(gamma + c0, ga); load_param<N>(beta + c0, be); }
+    if (RELU == 2) { load_param<N>(gamma + c0, ga); load_param<N>(beta + c0, be); }
   }
-  for_pixels<T>(g, [&](int, long long, long long pix, int c) {
-    float d[N], xv[N], yv[N], o[N];
-    load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
-    load_vec<T>(x + (size_t)pix * x_cs + x_coff + c, xv);
-    if (relu == 1) load_vec<T>(y + (size_t)pix * y_cs + y_coff + c, yv);
+  for_pixels_mlp<T, NTEN>(
+      g,
+      [&](long long pix, int c, uint4 (&raw)[NTEN]) {
+        raw[0] = load_raw<T>(dy + (size_t)pix * dy_cs + dy_coff + c);
+        raw[1] = load_raw<T>(x + (size_t)pix * x_cs + x_coff + c);
+        if constexpr (RELU == 1) raw[2] = load_raw<T>(y + (size_t)pix * y_cs + y_coff + c);
+      },
+      [&](long long, long long pix, int c, const uint4 (&raw)[NTEN]) {
+        float d[N], xv[N], yv[N], o[N];
+        unpack<T>(raw[0], d);
+        unpack<T>(raw[1], xv);
+        if constexpr (RELU == 1) unpack<T>(raw[2], yv);
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const float xhat = (xv[k] - mu[k]) * is[k];
-      const bool off = relu == 1 ? !(yv[k] > 0.f) : (relu == 2 ? !(ga[k] * xhat + be[k] > 0.f) : false);
-      const float dz = off ? 0.f : d[k];
-      d[k] = dz;
-      o[k] = k0[k] * (dz - ka[k] - xhat * kb[k]);
-    }
-    store_vec<T>(dx + (size_t)pix * C + c, o);
-    if (dres) store_vec<T>(dres + (size_t)pix * C + c, d);
-  });
+        for (int k = 0; k < N; ++k) {
+          const float xhat = (xv[k] - mu[k]) * is[k];
+          const bool off = RELU == 1 ? !(yv[k] > 0.f) : (RELU == 2 ? !(ga[k] * xhat + be[k] > 0.f) : false);
+          const float dz = off ? 0.f : d[k];
+          d[k] = dz;
+          o[k] = k0[k] * (dz - ka[k] - xhat * kb[k]);
+        }
+        store_vec<T>(dx + (size_t)pix * C + c, o);
+        if (dres) store_vec<T>(dres + (size_t)pix * C + c, d);
+      });
 }
 
 // ---------------------------------------------------------------- ReLU backward + bias gradient
-template <typename T>
+template <typename T, bool RELU>
 __global__ __launch_bounds__(TX * TY) void act_bwd_kernel(const T* __restrict__ dy, int dy_cs, int dy_coff,
                                                          const T* __restrict__ y, int y_cs, int relu,
                                                          T* __restrict__ dz, int dz_cs, RedGeom g,
                                                          float* __restrict__ partial) {
   constexpr int N = V<T>::N;
-  reduce_pixels<T, 1>(g, partial, [&](long long pix, int c, float (&acc)[1][N]) {
-    float d[N], yv[N];
-    load_vec<T>(dy + (size_t)pix * dy_cs + dy_coff + c, d);
-    if (relu) load_vec<T>(y + (size_t)pix * y_cs + c, yv);
+  constexpr int NTEN = RELU ? 2 : 1;
+  (void)relu;
+  reduce_pixels_mlp<T, 1, NTEN>(
+      g, partial,
+      [&](long long pix, int c, uint4 (&raw)[NTEN]) {
+        raw[0] = load_raw<T>(dy + (size_t)pix * dy_cs + dy_coff + c);
+        if constexpr (RELU) raw[1] = load_raw<T>(y + (size_t)pix * y_cs + c);
+      },
+      [&](long long pix, int c, const uint4 (&raw)[NTEN], float (&acc)[1][N]) {
+        float d[N], yv[N];
+        unpack<T>(raw[0], d);
+        if constexpr (RELU) unpack<T>(raw[1], yv);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      if (relu && !(yv[i] > 0.f)) d[i] = 0.f;
-      acc[0][i] += d[i];
-    }
-    if (dz) store_vec<T>(dz + (size_t)pix * dz_cs + c, d);
-  });
+        for (int i = 0; i < N; ++i) {
+          if (RELU && !(yv[i] > 0.f)) d[i] = 0.f;
+          acc[0][i] += d[i];
+        }
+        if (dz) store_vec<T>(dz + (size_t)pix * dz_cs + c, d);
+      });
 }
 
 __global__ void sum_rows_kernel(const float* __restrict__ partial, int rows, int K, int k, int C, float* __restrict__ out) {
@@ -459,16 +522,27 @@ __global__ __launch_bounds__(TX * TY) void gate_pool_kernel(const T* __restrict_
   for (int i = 0; i < N; ++i) { s[i] = 0.f; m[i] = -INFINITY; idx[i] = 0x7fffffff; }
   const long long p0 = chunk * g.chunk_pix;
   const long long p1 = (p0 + g.chunk_pix < g.npix) ? p0 + g.chunk_pix : g.npix;
-  if (c < g.C)
-    for (long long p = p0 + ty * g.pl + lm.sub; p < p1; p += TY * g.pl) {
+  if (c < g.C) {
+    const long long step = TY * g.pl;
+    long long p = p0 + ty * g.pl + lm.sub;
+    auto take = [&](const uint4& raw, long long pp) {
       float f[N];
-      load_vec<T>(x + ((size_t)seg * g.npix + p) * g.C + c, f);
+      unpack<T>(raw, f);
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         s[i] += f[i];
-        if (f[i] > m[i]) { m[i] = f[i]; idx[i] = (int)p; }
+        if (f[i] > m[i]) { m[i] = f[i]; idx[i] = (int)pp; }
       }
+    };
+    for (; p + (PIX_FLY - 1) * step < p1; p += PIX_FLY * step) {      // four pixels in flight (see reduce_pixels_mlp)
+      uint4 raw[PIX_FLY];
+#pragma unroll
+      for (int u = 0; u < PIX_FLY; ++u) raw[u] = load_raw<T>(x + ((size_t)seg * g.npix + p + u * step) * g.C + c);
+#pragma unroll
+      for (int u = 0; u < PIX_FLY; ++u) take(raw[u], p + u * step);
     }
+    for (; p < p1; p += step) take(load_raw<T>(x + ((size_t)seg * g.npix + p) * g.C + c), p);
+  }
 #pragma unroll
   for (int i = 0; i < N; ++i) { rs[ty][tx * N + i] = s[i]; rm[ty][tx * N + i] = m[i]; ri[ty][tx * N + i] = idx[i]; }
   __syncthreads();
@@ -533,13 +607,15 @@ __global__ __launch_bounds__(TX * TY) void gate_scale_kernel(const T* __restrict
   float sv[N];
   const int c0 = lane_map<N>(g).c;
   if (c0 < g.C) load_param<N>(s + (size_t)(blockIdx.x / g.chunks) * g.C + c0, sv);
-  for_pixels<T>(g, [&](int, long long, long long pix, int c) {
-    float f[N];
-    load_vec<T>(x + (size_t)pix * g.C + c, f);
+  for_pixels_mlp<T, 1>(
+      g, [&](long long pix, int c, uint4 (&raw)[1]) { raw[0] = load_raw<T>(x + (size_t)pix * g.C + c); },
+      [&](long long, long long pix, int c, const uint4 (&raw)[1]) {
+        float f[N];
+        unpack<T>(raw[0], f);
 #pragma unroll
-    for (int k = 0; k < N; ++k) f[k] *= sv[k];
-    store_vec<T>(y + (size_t)pix * g.C + c, f);
-  });
+        for (int k = 0; k < N; ++k) f[k] *= sv[k];
+        store_vec<T>(y + (size_t)pix * g.C + c, f);
+      });
 }
 
 // ds[b,c] = sum_p dy*x
@@ -547,13 +623,19 @@ template <typename T>
 __global__ __launch_bounds__(TX * TY) void gate_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                                  RedGeom g, float* __restrict__ partial) {
   constexpr int N = V<T>::N;
-  reduce_pixels<T, 1>(g, partial, [&](long long pix, int c, float (&acc)[1][N]) {
-    float d[N], xv[N];
-    load_vec<T>(dy + (size_t)pix * g.C + c, d);
-    load_vec<T>(x + (size_t)pix * g.C + c, xv);
+  reduce_pixels_mlp<T, 1, 2>(
+      g, partial,
+      [&](long long pix, int c, uint4 (&raw)[2]) {
+        raw[0] = load_raw<T>(dy + (size_t)pix * g.C + c);
+        raw[1] = load_raw<T>(x + (size_t)pix * g.C + c);
+      },
+      [&](long long, int, const uint4 (&raw)[2], float (&acc)[1][N]) {
+        float d[N], xv[N];
+        unpack<T>(raw[0], d);
+        unpack<T>(raw[1], xv);
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[0][i] += d[i] * xv[i];
-  });
+        for (int i = 0; i < N; ++i) acc[0][i] += d[i] * xv[i];
+      });
 }
 
 __global__ void gate_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ ds) {
@@ -588,13 +670,15 @@ __global__ __launch_bounds__(TX * TY) void gate_bwd_apply_kernel(const T* __rest
 #pragma unroll
     for (int k = 0; k < N; ++k) { am[k] = amax[o + k]; da[k] *= inv; }
   }
-  for_pixels<T>(g, [&](int, long long p, long long pix, int c) {
-    float f[N];
-    load_vec<T>(dy + (size_t)pix * g.C + c, f);
+  for_pixels_mlp<T, 1>(
+      g, [&](long long pix, int c, uint4 (&raw)[1]) { raw[0] = load_raw<T>(dy + (size_t)pix * g.C + c); },
+      [&](long long p, long long pix, int c, const uint4 (&raw)[1]) {
+        float f[N];
+        unpack<T>(raw[0], f);
 #pragma unroll
-    for (int k = 0; k < N; ++k) f[k] = f[k] * sv[k] + da[k] + (am[k] == (int)p ? dm[k] : 0.f);
-    store_vec<T>(dx + (size_t)pix * g.C + c, f);
-  });
+        for (int k = 0; k < N; ++k) f[k] = f[k] * sv[k] + da[k] + (am[k] == (int)p ? dm[k] : 0.f);
+        store_vec<T>(dx + (size_t)pix * g.C + c, f);
+      });
 }
 
 int ew_blocks(long long total) {
@@ -667,9 +751,11 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
   if (int e = check_launch("bn_finalize")) return e;
   if (!y) return JSPSR_OK;      // statistics + (scale | shift) only: the consumer applies them (res_affine)
   const RedGeom ga = make_red(npix, 1, C, vec);
-  DISPATCH(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, red_grid(ga, vec), dim3(TX, TY), 0, s,
-                                     static_cast<const T*>(x), x_cs, x_coff, static_cast<const T*>(res), r_cs, r_coff,
-                                     static_cast<T*>(y), y_cs, y_coff, scale, shift, res_affine, res_scale, relu, ga));
+#define BN_APPLY(R) DISPATCH(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, R>), red_grid(ga, vec), dim3(TX, TY), 0, s,             \
+                                     static_cast<const T*>(x), x_cs, x_coff, static_cast<const T*>(res), r_cs, r_coff,        \
+                                     static_cast<T*>(y), y_cs, y_coff, scale, shift, res_affine, res_scale, relu, ga))
+  if (res) { BN_APPLY(true); } else { BN_APPLY(false); }
+#undef BN_APPLY
   return check_launch("bn_apply");
 }
 
@@ -690,17 +776,21 @@ extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_co
   float* coef = ws;
   float* partial = ws + 3 * C;
   const RedGeom g = make_red(npix, 1, C, vec);
-  DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
-                                     static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
-                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, relu, g, partial));
+#define BN_BWD_REDUCE(R) DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R>), red_grid(g, vec), dim3(TX, TY), 0, s, \
+                                     static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,     \
+                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, g, partial))
+  if (relu == 0) { BN_BWD_REDUCE(0); } else if (relu == 1) { BN_BWD_REDUCE(1); } else { BN_BWD_REDUCE(2); }
+#undef BN_BWD_REDUCE
   if (int e = check_launch("bn_bwd_reduce")) return e;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, C, npix, gamma,
                      save_invstd, training, res_scale, accumulate, dgamma, dbeta, coef);
   if (int e = check_launch("bn_bwd_finalize")) return e;
-  DISPATCH(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s,
-                                     static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,
-                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, coef, relu,
-                                     static_cast<T*>(dx), static_cast<T*>(dres), g));
+#define BN_BWD_APPLY(R) DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), red_grid(g, vec), dim3(TX, TY), 0, s,  \
+                                     static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,     \
+                                     static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, coef,     \
+                                     static_cast<T*>(dx), static_cast<T*>(dres), g))
+  if (relu == 0) { BN_BWD_APPLY(0); } else if (relu == 1) { BN_BWD_APPLY(1); } else { BN_BWD_APPLY(2); }
+#undef BN_BWD_APPLY
   return check_launch("bn_bwd_apply");
 }
 
@@ -724,8 +814,10 @@ extern "C" int jspsr_act_backward(int dtype, const void* dy, int dy_cs, int dy_c
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   const RedGeom g = make_red(npix, 1, C, vec);
-  DISPATCH(dtype, hipLaunchKernelGGL(act_bwd_kernel<T>, red_grid(g, vec), dim3(TX, TY), 0, s, static_cast<const T*>(dy),
-                                     dy_cs, dy_coff, static_cast<const T*>(y), y_cs, relu, static_cast<T*>(dz), dz_cs, g, partial));
+#define ACT_BWD(R) DISPATCH(dtype, hipLaunchKernelGGL((act_bwd_kernel<T, R>), red_grid(g, vec), dim3(TX, TY), 0, s, static_cast<const T*>(dy), \
+                                     dy_cs, dy_coff, static_cast<const T*>(y), y_cs, relu, static_cast<T*>(dz), dz_cs, g, partial))
+  if (relu) { ACT_BWD(true); } else { ACT_BWD(false); }
+#undef ACT_BWD
   if (int e = check_launch("act_backward")) return e;
   if (dbias) {
     hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, 1, 0, C, dbias);
