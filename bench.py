@@ -59,8 +59,9 @@ def time_k1(model, inputs, iters=20):
     """Roofline of K1 (the HBM-bound propagation kernels) at this batch's shape.
 
     Each kernel is launched `iters` times back to back through the C ABI between two events
-    recorded on the launch stream (torch's current stream is the stream handed to the ABI), so the
-    figure is the average launch duration incl. the ~1-2 us inter-launch gap.  Operand sets rotate
+    recorded on the launch stream (torch's current stream is the stream handed to the ABI), behind
+    300 warm-up launches of the same kernel, so the figure is the steady-state average launch
+    duration incl. the ~1-2 us inter-launch gap.  Operand sets rotate
     over > 256 MiB so the Infinity Cache cannot serve them.
     """
     from jspsr_amd import ops
@@ -90,15 +91,17 @@ def time_k1(model, inputs, iters=20):
         ops.prop_backward_raw(gout, dem, sets[i % nset][0], sets[i % nset][1], w, gsets[i % nset][0],
                               gsets[i % nset][1], gw, gb, ws)
 
-    def timed(fn, reps=3):
-        """Mean launch duration (s) of `iters` back-to-back launches between two events on the launch stream; the MEDIAN of
-        `reps` such measurements (the first block after the training loop can run at a different clock), all reps kept."""
+    def timed(fn, reps=3, warm=300):
+        """Mean launch duration (s) of `iters` back-to-back launches between two events on the launch stream, in STEADY
+        STATE: `warm` launches of the same kernel (~25 ms) run straight into the timed ones, with no synchronisation in
+        between.  Timing 20 launches behind three warm-ups and a synchronize() -- what this leg did until round 3 -- lands
+        in the chip's clock transient after an idle bubble: the same backward kernel reads 82-91 us there and 77.5 us
+        from 300 warm-up launches on (profiles/r03_k1_warmup_transient.txt).  The MEDIAN of `reps` measurements, all kept."""
         out = []
         for _ in range(reps):
-            for i in range(3):
+            for i in range(warm):
                 fn(i)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
             e0.record()
             for i in range(iters):
                 fn(i)

@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jspsr_amd import ops  # noqa: E402
 
 
+WARM = int(os.environ.get("K1_LAB_WARM", "300"))    # warm-up launches in front of every timed block
+
+
 def main():
     a = sys.argv[1:]
     B, H, W = (int(a[0]), int(a[1]), int(a[2])) if len(a) >= 3 else (8, 512, 512)
@@ -35,10 +38,9 @@ def main():
     for name, fn, nbytes in (("fwd", fwd, 108.0 * px), ("bwd", bwd, 208.0 * px)):
         best = 1e9
         for rep in range(3):
-            for i in range(3):
+            for i in range(WARM):      # steady state: see bench.py time_k1 / profiles/r03_k1_warmup_transient.txt
                 fn(i)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
             e0.record()
             for i in range(20):
                 fn(i)
@@ -66,10 +68,9 @@ def main():
                                       ("bwd", hb, (64 * es + 8.0) * px, (50 * es + 8.0) * px)):
             best = 1e9
             for rep in range(3):
-                for i in range(3):
+                for i in range(WARM):
                     fn(i)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
                 e0.record()
                 for i in range(20):
                     fn(i)
