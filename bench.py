@@ -68,6 +68,7 @@ def time_k1(model, inputs, iters=20):
     dem = inputs[0]
     B, _, H, W = dem.shape
     dev = dem.device
+    torch.cuda.empty_cache()    # operand sets in fresh allocations, as in tools/k1_lab.py (not carved out of the step's cached blocks)
     g = torch.Generator(device=dev).manual_seed(1)
     nset = max(2, int(700e6 // (B * H * W * 4 * 26)) + 1)
     sets = [(torch.sigmoid(torch.randn(B, 9, H, W, device=dev, generator=g)),
