@@ -122,7 +122,10 @@ dim3 red_grid(const RedGeom& g, int vec) { return dim3(g.nseg * g.chunks, (g.C /
 // works through them, in pixel order (so sums keep their order and their bits).  One pixel per trip left 2-3 x 16 bytes
 // per lane in flight -- about 32 KB per CU at 16 waves, under half of what hides an HBM miss; the BatchNorm backward
 // pair ran at 4.5 TB/s effective where a plain stream reaches 5.5 (tools/bench_bn.py).
-constexpr int PIX_FLY = 4;
+#ifndef K4_PIX_FLY
+#define K4_PIX_FLY 4      // (lab builds: -DK4_PIX_FLY=2|8)
+#endif
+constexpr int PIX_FLY = K4_PIX_FLY;
 template <typename T, int K, int NTEN, typename L, typename F>
 __device__ __forceinline__ void reduce_pixels_mlp(const RedGeom& g, float* __restrict__ partial, L&& load, F&& use) {
   constexpr int N = V<T>::N;
