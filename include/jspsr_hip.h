@@ -122,6 +122,41 @@ int jspsr_prop_head_backward(int dtype, const float* grad_out, const float* dem,
                              void* grad_head, float* grad_wk, float* grad_b0, void* workspace, int B, int H, int W,
                              jspsr_stream_t stream);
 
+/* ---- K1 in the models (round 4): logits + offsets as PLANES of one tensor ---------------------------------------
+ * The same operator as jspsr_prop_forward_f32 / jspsr_prop_backward_f32 -- same kernels, same 108 / 208 algorithmic bytes
+ * per pixel -- with what the reference does between the generator's heads and deform_conv2d folded in: the Sigmoid of
+ * conv_weight (models/components/spn.py:43), the zero centre offset (spn.py:69-73), the mean subtraction
+ * (spn.py:100-101), the residual (spn.py:116-117).
+ *   head [B][25][H][W] fp32: planes 0..8 affinity LOGITS of tap k (row-major over the 3x3 window), planes 9..24 the sixteen
+ *   learned offsets in Generator's order (dy, dx of taps 0..3, 5..8) -- what jspsr_head_forward writes.
+ * Backward: grad_head in the same layout = d/d(head) (sigmoid derivative included); grad_wk / grad_b0 overwritten, or both
+ * NULL to leave the partial rows in the workspace (jspsr_prop_backward_workspace_bytes; jspsr_prop_backward_fold_f32).
+ * Any W and 4-byte aligned pointers; 16-byte aligned pointers with W % 4 == 0 take the persistent LDS-DMA kernel. */
+int jspsr_prop_logits_forward_f32(const float* dem, const float* head, const float* wk, const float* b0, float scale,
+                                  float* out, int B, int H, int W, jspsr_stream_t stream);
+int jspsr_prop_logits_backward_f32(const float* grad_out, const float* dem, const float* head, const float* wk,
+                                   float* grad_head, float* grad_wk, float* grad_b0, void* workspace, int B, int H, int W,
+                                   jspsr_stream_t stream);
+
+/* ---- K1c: the generator's two 1x1 heads as one convolution that writes planes -------------------------------------
+ * Replaces conv_weight (without its Sigmoid) and conv_offset of Generator.forward, models/components/spn.py:41-52,66-68
+ * (and BasicDepthEncoder's heads, models/LRRU.py:238-247), and their autograd.
+ *   x      NHWC feature (B,H,W,Cin) of `dtype` (0 fp32 / 1 bf16, as JSPSR_F32 / JSPSR_BF16 below), channel pitch x_cstride,
+ *          first channel x_coff (elements; multiples of 4 fp32 / 8 bf16), 16-byte aligned
+ *   w25    [25][Cin] fp32: rows 0..8 = conv_weight.0.weight, rows 9..24 = conv_offset.conv.0.weight;  b25 [25] the biases
+ *   planes [B][25][H][W] fp32 = the `head` operand of jspsr_prop_logits_forward_f32
+ * jspsr_head_ok(dtype, B, H, W, Cin) != 0: H * W a multiple of 32, Cin in {32, 64, 128}.
+ * Backward, one pass over grad_planes [B][25][H][W]: grad_x (NHWC, `dtype`, pitch / offset as x; NULL = not wanted),
+ * grad_nhwc32 [B][H][W][32] in `dtype` (channels 25..31 zero) = the G operand jspsr_conv2d_wgrad takes for the weight
+ * gradient, grad_b25 [25] (overwritten).  workspace: jspsr_head_backward_workspace_bytes(), 16-byte aligned. */
+int jspsr_head_ok(int dtype, int B, int H, int W, int Cin);
+int jspsr_head_forward(int dtype, const void* x, int x_cstride, int x_coff, int Cin, const float* w25, const float* b25,
+                       float* planes, int B, int H, int W, jspsr_stream_t stream);
+size_t jspsr_head_backward_workspace_bytes(int B, int H, int W);
+int jspsr_head_backward(int dtype, const float* grad_planes, const float* w25, int Cin, void* grad_x, int gx_cstride,
+                        int gx_coff, void* grad_nhwc32, float* grad_b25, void* workspace, int B, int H, int W,
+                        jspsr_stream_t stream);
+
 /* ---- K2: convolutions on the matrix cores (implicit GEMM, NHWC) ---------------------------
  * Replace the reference's nn.Conv2d / nn.ConvTranspose2d calls and their autograd
  * (models/components/basics.py:6-20,39-47,69-77; every conv of models/JSPSR.py:66-180 and

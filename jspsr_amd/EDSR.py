@@ -70,7 +70,4 @@ class EDSR(HotPathModule):
                 h = blk(h)
             tail = self.encoder[-1]
             h = E.conv2d(h, tail.weight, tail.bias, 1, 1) + self.res_scale * xs
-            head = self.generator.head(self.generator.features(E.from_nchw(dem), h))
-            if E._offset_probe is not None:
-                E._offset_probe.append(ops.split_head(head)[1])
-            return self.post_layer.from_head(dem.float(), head)
+            return self.post_layer.from_feature(dem.float(), self.generator.features(E.from_nchw(dem), h), self.generator)

@@ -232,9 +232,7 @@ class Model(HotPathModule):
             x = buf.join([up(x, dest=(buf, 0))] + joined[s], 0, defer=nb if defer_skip else 0)
         c0 = self.conv0(x)
         dem = dem.detach()  # :372
-        head = self.generator.head(self.generator.features(dem_a.detach(), c0))
-        if E._offset_probe is not None:
-            E._offset_probe.append(ops.split_head(head)[1])
-        # K1h reads the merged head's NHWC output where it lies (sigmoid, zero centre offset, mean subtraction,
-        # gather, residual: one kernel; its backward writes the head's gradient in the same layout)
-        return self.postprocessor.from_head(dem.float(), head)
+        # the two 1x1 heads write the planes the propagation kernel reads (sigmoid, zero centre offset, mean subtraction,
+        # gather, residual: one kernel -- the one of the public PostProcessor boundary; engine.heads_propagate)
+        feature = self.generator.features(dem_a.detach(), c0)
+        return self.postprocessor.from_feature(dem.float(), feature, self.generator)

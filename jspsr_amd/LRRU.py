@@ -66,6 +66,12 @@ class DepthEncoder(nn.Module):
         weight = E.sigmoid(E.conv2d(x, self.conv_weight.weight, self.conv_weight.bias))
         return weight, E.conv2d(x, self.conv_offset.weight, self.conv_offset.bias)
 
+    def features(self, depth, context):
+        """The 2c-channel feature the two 1x1 heads read (LRRU.py:226-237)."""
+        d = self.convd2(self.convd1(depth))
+        f = self.convf2(self.convf1(context))
+        return self.ref(self.conv(E.cat((d, f))))
+
     def head(self, depth, context):
         """Same features, the two 1x1 heads as one tap-major 32-channel convolution (affinity logits + offsets) for
         the head-fed propagation kernel (ops.merge_heads / ops.propagate_head)."""
@@ -157,10 +163,8 @@ class Model(HotPathModule):
     def _step(self, current, context, enc):
         """One propagation step on the detached running estimate (LRRU.py:453-455 etc.)."""
         current = current.detach().float().contiguous()
-        head = enc.head(E.from_nchw(current), context)
-        if E._offset_probe is not None:
-            E._offset_probe.append(ops.split_head(head)[1])
-        return E.propagate_head(current, head, self.Post_process.w, self.Post_process.b, 1.0)
+        return E.heads_propagate(current, enc.features(E.from_nchw(current), context), enc.conv_weight, enc.conv_offset,
+                                 self.Post_process.w, self.Post_process.b, 1.0)
 
     def _keep_input(self, out, d_clear):
         """preserve_input blend (LRRU.py:447-450): valid input pixels overwrite the estimate."""

@@ -50,7 +50,7 @@ int check_launch(const char* what) {
 
 }  // namespace jspsr
 
-extern "C" int jspsr_abi_version(void) { return 13; }
+extern "C" int jspsr_abi_version(void) { return 14; }
 extern "C" long long jspsr_launch_count(const char* what) {
   if (!what) return -1;
   long long n = 0;

@@ -29,6 +29,10 @@ int prop_dma_max_rows();
 bool prop_dma_ok(int B, int H, int W, int oc, std::initializer_list<const void*> ptrs);
 int prop_dma_forward(const float* dem, const float* weight, const float* offset, int oc, const float* wk, const float* b0,
                      float scale, float* out, int B, int H, int W, hipStream_t s);
+int prop_dma_logits_forward(const float* dem, const float* head, const float* wk, const float* b0, float scale, float* out,
+                            int B, int H, int W, hipStream_t s);
+int prop_dma_logits_backward(const float* gout, const float* dem, const float* head, const float* wk, float* ghead, float* partial,
+                             int B, int H, int W, hipStream_t s);
 int prop_dma_backward(const float* gout, const float* dem, const float* weight, const float* offset, int oc, const float* wk,
                       float* gweight, float* goffset, float* partial, int B, int H, int W, hipStream_t s);
 }  // namespace jspsr
@@ -88,13 +92,15 @@ __device__ __forceinline__ constexpr int och(int k, int c) {
 // Lane -> pixel map: a row of the tile is TW/PX lanes wide; a workgroup pass covers
 // RPP = NT*PX/TW rows and the tile's TH rows take TH/RPP passes (not unrolled: it bounds the
 // live registers to one pass; occupancy, not unrolling, hides the HBM latency).
-template <int OC, int PX, bool VEC, int TH, int TW>
+// SIG: the affinity planes hold logits (sigmoid applied here; the backward writes d/d(logit)) -- jspsr_prop_logits_*.
+// wbs / obs: elements between consecutive images of weight / offset (9 P / OC P at the public boundary).
+template <int OC, int PX, bool VEC, int TH, int TW, bool SIG = false>
 __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ dem,
                                                      const float* __restrict__ weight,
                                                      const float* __restrict__ offset,
                                                      const float* __restrict__ wk,
                                                      const float* __restrict__ b0, float scale,
-                                                     float* __restrict__ out, Geom g) {
+                                                     float* __restrict__ out, Geom g, size_t wbs, size_t obs) {
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float lds[LH * LW];
   constexpr int LPR = TW / PX;       // lanes per tile row
@@ -116,11 +122,17 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
 #pragma unroll 1
   for (int y = ty0 + threadIdx.x / LPR; y < min(ty0 + TH, H); y += RPP) {
     const size_t pix = (size_t)y * W + x;
-    const float* wp = weight + (size_t)b * 9 * P + pix;
-    const float* op = offset + (size_t)b * OC * P + pix;
+    const float* wp = weight + (size_t)b * wbs + pix;
+    const float* op = offset + (size_t)b * obs + pix;
     Vec<PX> a[9], oy[9], ox[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = ldv<PX, VEC>(wp + k * P, x, W);
+    for (int k = 0; k < 9; ++k) {
+      a[k] = ldv<PX, VEC>(wp + k * P, x, W);
+      if (SIG) {
+#pragma unroll
+        for (int j = 0; j < PX; ++j) a[k].v[j] = __builtin_amdgcn_rcpf(1.f + __expf(-a[k].v[j]));
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       if (OC == 18 || k != 4) {
@@ -154,12 +166,12 @@ __global__ __launch_bounds__(NT) void prop_fwd_kernel(const float* __restrict__ 
   }
 }
 
-template <int OC, int PX, bool VEC, int TH, int TW>
+template <int OC, int PX, bool VEC, int TH, int TW, bool SIG = false>
 __global__ __launch_bounds__(NT) void prop_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ dem,
     const float* __restrict__ weight, const float* __restrict__ offset,
     const float* __restrict__ wk, float* __restrict__ gweight, float* __restrict__ goffset,
-    float* __restrict__ partial, Geom g) {      // partial: 16-byte header (row count) + one row per workgroup
+    float* __restrict__ partial, Geom g, size_t wbs, size_t obs) {      // partial: 16-byte header (row count) + one row per workgroup
   constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
   __shared__ __attribute__((aligned(16))) float lds[LH * LW];
   __shared__ float red[NT / 64][NRED];
@@ -186,13 +198,19 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
 #pragma unroll 1
     for (int y = ty0 + threadIdx.x / LPR; y < min(ty0 + TH, H); y += RPP) {
       const size_t pix = (size_t)y * W + x;
-      const float* wp = weight + (size_t)b * 9 * P + pix;
-      const float* op = offset + (size_t)b * OC * P + pix;
-      float* gop = goffset + (size_t)b * OC * P + pix;
-      float* gwp = gweight + (size_t)b * 9 * P + pix;
+      const float* wp = weight + (size_t)b * wbs + pix;
+      const float* op = offset + (size_t)b * obs + pix;
+      float* gop = goffset + (size_t)b * obs + pix;
+      float* gwp = gweight + (size_t)b * wbs + pix;
       Vec<PX> a[9], oy[9], ox[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) a[k] = ldv<PX, VEC>(wp + k * P, x, W);
+      for (int k = 0; k < 9; ++k) {
+        a[k] = ldv<PX, VEC>(wp + k * P, x, W);
+        if (SIG) {
+#pragma unroll
+          for (int j = 0; j < PX; ++j) a[k].v[j] = __builtin_amdgcn_rcpf(1.f + __expf(-a[k].v[j]));
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         if (OC == 18 || k != 4) {
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(NT) void prop_bwd_kernel(
         }
         gsum /= 9.f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) gm[k].v[j] -= gsum;
+        for (int k = 0; k < 9; ++k) gm[k].v[j] = SIG ? (gm[k].v[j] - gsum) * a[k].v[j] * (1.f - a[k].v[j]) : gm[k].v[j] - gsum;
         sums[9] += gj;
       }
 #pragma unroll
@@ -370,7 +388,7 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
   by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
     hipLaunchKernelGGL((prop_fwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
                                         decltype(THc)::value, decltype(TWc)::value>),
-                       grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g);
+                       grid, block, 0, s, dem, weight, offset, wk, b0, scale, out, g, (size_t)9 * H * W, (size_t)offset_channels * H * W);
   });
   return jspsr::check_launch("prop_forward");
 }
@@ -378,7 +396,9 @@ extern "C" int jspsr_prop_forward_f32(const float* dem, const float* weight, con
 extern "C" size_t jspsr_prop_backward_workspace_bytes(int B, int H, int W) {
   Geom g;
   if (make_geom(B, H, W, g)) return 0;
-  const size_t rows = (size_t)g.nblk > (size_t)jspsr::prop_dma_max_rows() ? (size_t)g.nblk : (size_t)jspsr::prop_dma_max_rows();
+  size_t rows = (size_t)g.nblk > (size_t)jspsr::prop_dma_max_rows() ? (size_t)g.nblk : (size_t)jspsr::prop_dma_max_rows();
+  const size_t rows_8x64 = (size_t)B * ((W + 63) / 64) * ((H + 7) / 8);      // jspsr_prop_logits_backward_f32's general path
+  if (rows_8x64 > rows) rows = rows_8x64;
 #ifdef K1D_STAMPS
   return 16 + 4096 * NRED * sizeof(float) + (1 << 20);                  // lab build: cycle stamps behind the rows
 #endif
@@ -413,7 +433,8 @@ extern "C" int jspsr_prop_backward_f32(const float* grad_out, const float* dem, 
     by_shape(offset_channels, px, vec, g.th, g.tw, [&](auto OCc, auto PXc, auto VECc, auto THc, auto TWc) {
       hipLaunchKernelGGL((prop_bwd_kernel<decltype(OCc)::value, decltype(PXc)::value, decltype(VECc)::value != 0,
                                           decltype(THc)::value, decltype(TWc)::value>),
-                         grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g);
+                         grid, block, 0, s, grad_out, dem, weight, offset, wk, grad_weight, grad_offset, partial, g,
+                         (size_t)9 * H * W, (size_t)offset_channels * H * W);
     });
     if (int e = jspsr::check_launch("prop_backward")) return e;
   }
@@ -430,4 +451,55 @@ extern "C" int jspsr_prop_backward_fold_f32(const void* workspace, int B, int H,
   hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(workspace), -1, grad_wk, grad_b0);
   return jspsr::check_launch("prop_backward_fold");
+}
+
+// ---- the in-model form: logits + offsets as planes of ONE (B,25,H,W) tensor (include/jspsr_hip.h, jspsr_prop_logits_*) ----
+extern "C" int jspsr_prop_logits_forward_f32(const float* dem, const float* head, const float* wk, const float* b0, float scale,
+                                             float* out, int B, int H, int W, jspsr_stream_t stream) {
+  if (!dem || !head || !wk || !b0 || !out) return jspsr::fail(JSPSR_EINVAL, "prop_logits_forward: null pointer");
+  Geom g;
+  if (int e = make_geom(B, H, W, g)) return e;
+  for (const void* p : {(const void*)dem, (const void*)head, (const void*)out})
+    if (!jspsr::aligned4(p)) return jspsr::fail(JSPSR_EALIGN, "prop_logits_forward: pointer not 4-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (jspsr::prop_dma_ok(B, H, W, 16, {dem, head, out}))
+    return jspsr::prop_dma_logits_forward(dem, head, wk, b0, scale, out, B, H, W, s);
+  // general shapes (W % 4 != 0, unaligned operands): the one-pixel-per-lane kernel on 64 x 8 tiles
+  g.th = 8; g.tw = 64;
+  g.tiles_x = (W + 63) / 64; g.tiles_y = (H + 7) / 8;
+  g.nblk = B * g.tiles_x * g.tiles_y;
+  g.dem_vec4 = can_vec(W, 4, {dem});
+  const size_t P = (size_t)H * W;
+  hipLaunchKernelGGL((prop_fwd_kernel<16, 1, true, 8, 64, true>), dim3(g.nblk), dim3(NT), 0, s, dem, head, head + 9 * P, wk, b0, scale,
+                     out, g, 25 * P, 25 * P);
+  return jspsr::check_launch("prop_logits_forward");
+}
+
+extern "C" int jspsr_prop_logits_backward_f32(const float* grad_out, const float* dem, const float* head, const float* wk,
+                                              float* grad_head, float* grad_wk, float* grad_b0, void* workspace, int B, int H,
+                                              int W, jspsr_stream_t stream) {
+  if (!grad_out || !dem || !head || !wk || !grad_head || !workspace || (!grad_wk != !grad_b0))
+    return jspsr::fail(JSPSR_EINVAL, "prop_logits_backward: null pointer");
+  Geom g;
+  if (int e = make_geom(B, H, W, g)) return e;
+  for (const void* p : {(const void*)grad_out, (const void*)dem, (const void*)head, (const void*)grad_head})
+    if (!jspsr::aligned4(p)) return jspsr::fail(JSPSR_EALIGN, "prop_logits_backward: pointer not 4-byte aligned");
+  if (!jspsr::aligned16(workspace)) return jspsr::fail(JSPSR_EALIGN, "prop_logits_backward: workspace not 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  if (jspsr::prop_dma_ok(B, H, W, 16, {grad_out, dem, head, grad_head})) {
+    if (int e = jspsr::prop_dma_logits_backward(grad_out, dem, head, wk, grad_head, partial, B, H, W, s)) return e;
+  } else {
+    g.th = 8; g.tw = 64;
+    g.tiles_x = (W + 63) / 64; g.tiles_y = (H + 7) / 8;
+    g.nblk = B * g.tiles_x * g.tiles_y;
+    g.dem_vec4 = can_vec(W, 4, {dem});
+    const size_t P = (size_t)H * W;
+    hipLaunchKernelGGL((prop_bwd_kernel<16, 1, true, 8, 64, true>), dim3(g.nblk), dim3(NT), 0, s, grad_out, dem, head, head + 9 * P, wk,
+                       grad_head, grad_head + 9 * P, partial, g, 25 * P, 25 * P);
+    if (int e = jspsr::check_launch("prop_logits_backward")) return e;
+  }
+  if (!grad_wk) return JSPSR_OK;
+  hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, -1, grad_wk, grad_b0);
+  return jspsr::check_launch("prop_backward_finalize");
 }

@@ -41,6 +41,9 @@ struct DmaArgs {
   float* partial;      // rows of NRED floats behind a 16-byte header holding the row count
   float scale;
   int B, H, W, tiles_x, tiles_y, ntiles;
+  // elements between consecutive images of weight / offset (and of their gradients): 9 P / OC P for the two tensors of the
+  // public boundary, 25 P for both when they are planes 0..8 / 9..24 of ONE (B,25,H,W) head tensor (SIG form)
+  size_t wbs, obs;
 };
 
 // One tile t of a workgroup's run, operand / DEM buffers t % 2.  Two roles:
@@ -50,7 +53,9 @@ struct DmaArgs {
 // SPLIT = true:  NW compute waves (0 .. NW-1) + NW mover waves (NW .. 2 NW-1); mover NW + w loads what compute wave w
 //                consumes, so a compute wave never pays the issue time of an LDS-DMA instruction (200-400 cycles each
 //                while the memory pipeline is backed up), and the tile's bytes are requested as soon as the barrier falls.
-template <int OC, int NW, bool BWD, bool NTL, bool SPLIT, int RP>
+// SIG: the nine affinity planes hold LOGITS (the generator head's raw output, spn.py:41-43): the sigmoid is applied here in
+// fp32, and the backward writes d/d(logit) = d/d(affinity) * a (1 - a) -- the in-model form (jspsr_prop_logits_*).
+template <int OC, int NW, bool BWD, bool NTL, bool SPLIT, int RP, bool SIG>
 __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop_dma_kernel(const DmaArgs A) {
   using C = DmaCfg<NW, OPB, RP>;
   constexpr int LH = C::LH, TH = C::TH;
@@ -58,7 +63,11 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
   constexpr int NPIECE = (NPL + 3) / 4;
   constexpr int NOUTPL = 9 + OC;                   // gradient planes written per row (backward)
   constexpr int NOPIECE = (NOUTPL + 3) / 4;
-  constexpr int NST = BWD ? NOPIECE : 1;           // vector-memory stores a valid row issues per tile
+  // vector-memory stores a valid row issues per tile -- the counted wait of the symmetric form relies on EVERY one of
+  // them being issued, i.e. on each store piece having a lane whose predicate holds on every valid row: lane sq = sc = 0
+  // (plane 4 i < NOUTPL for every i < NOPIECE, asserted below; x0 < W for every tile of the grid)
+  constexpr int NST = BWD ? NOPIECE : 1;
+  static_assert(4 * (NOPIECE - 1) < NOUTPL, "every store piece needs an always-active lane (counted vmcnt waits)");
   static_assert(NPIECE <= 7, "operand buffer is 7 pieces");
   __shared__ __attribute__((aligned(1024))) char smem[C::SMEM];
   __shared__ double red[NW][NRED];
@@ -132,8 +141,8 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
   auto issue_row = [&](int ib, int y, int x0, int obuf) __attribute__((always_inline)) {
     if (y < H) {       // wave-uniform
       const size_t pix = (size_t)y * W + x0;
-      const char* wb = reinterpret_cast<const char*>(A.weight + (size_t)ib * 9 * P + pix);
-      const char* ob = reinterpret_cast<const char*>(A.offset + (size_t)ib * OC * P + pix);
+      const char* wb = reinterpret_cast<const char*>(A.weight + (size_t)ib * A.wbs + pix);
+      const char* ob = reinterpret_cast<const char*>(A.offset + (size_t)ib * A.obs + pix);
       const char* gb = BWD ? reinterpret_cast<const char*>(A.gout + (size_t)ib * P + pix) : wb;
       const bool colok = x0 + lc * 4 < W;
       const unsigned dst0 = lds0 + 2 * C::DEMB + (obuf * NW + wave) * OPB;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
         const int ly0 = y0 - HALO, lx0 = x0 - HALO;
         float a[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a[k] = ob[k * 64 + lane];
+        for (int k = 0; k < 9; ++k) a[k] = SIG ? __builtin_amdgcn_rcpf(1.f + __expf(-ob[k * 64 + lane])) : ob[k * 64 + lane];   // v_exp + v_rcp
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) s += a[k];
@@ -263,7 +272,7 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
         } else {
           gsum /= 9.f;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) ob[k * 64 + lane] = gm[k] - gsum;
+          for (int k = 0; k < 9; ++k) ob[k * 64 + lane] = SIG ? (gm[k] - gsum) * a[k] * (1.f - a[k]) : gm[k] - gsum;
           dsum[9] += gj;
         }
       }
@@ -276,8 +285,8 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
         const int sq = lane_ >> 4, sc = lane_ & 15;
         const char* obc = reinterpret_cast<const char*>(ob);
         const size_t pix = (size_t)y * W + x0;
-        char* gwb = reinterpret_cast<char*>(A.gweight + (size_t)b * 9 * P + pix);
-        char* gob = reinterpret_cast<char*>(A.goffset + (size_t)b * OC * P + pix);
+        char* gwb = reinterpret_cast<char*>(A.gweight + (size_t)b * A.wbs + pix);
+        char* gob = reinterpret_cast<char*>(A.goffset + (size_t)b * A.obs + pix);
         const bool colok = x0 + sc * 4 < W;
         const unsigned plane_b = (unsigned)(P * 4);
         // two batches (4 + 3 pieces): all seven lifted at once cost 28 registers the compute part has no room for
@@ -354,7 +363,7 @@ struct Plan {
   bool ntl, split;
 };
 
-Plan make_plan(int B, int H, int W, bool bwd, DmaArgs& A) {
+Plan make_plan(int B, int H, int W, bool bwd, DmaArgs& A, bool lab_shapes = true) {
   // defaults = what measured best on MI355X; the environment is for A/B measurements
   static const int nw_env = env_int("JSPSR_PROP_NW", 4);
   static const int ntl_env = env_int("JSPSR_PROP_NTL", -1);
@@ -362,12 +371,12 @@ Plan make_plan(int B, int H, int W, bool bwd, DmaArgs& A) {
   static const int wgs_env = env_int("JSPSR_PROP_WGS", 0);     // workgroups per CU (0 = what the LDS admits)
   Plan p;
   static const int rp_env = env_int("JSPSR_PROP_RP", 0);        // rows per wave per tile (1, 2 or 4)
-  p.nw = nw_env == 8 ? 8 : 4;
+  p.nw = (lab_shapes && nw_env == 8) ? 8 : 4;      // (the SIG form is built for 4-wave, one-row-per-wave tiles only)
   p.ntl = ntl_env < 0 ? true : ntl_env != 0;
   p.split = split_env < 0 ? !bwd : split_env != 0;
   // several rows per wave under one staged DEM tile: symmetric waves only (they then meet once per TILE; split waves hand
   // rows over every slot anyway, and their 128-register budget has no room for the second loop level)
-  p.rp = (p.nw == 8 || p.split) ? 1 : (rp_env == 2 || rp_env == 4 ? rp_env : 1);      // measured equal within the noise (profiles/r03_k1_dma_rows_per_tile.txt): 1
+  p.rp = (p.nw == 8 || p.split || !lab_shapes) ? 1 : (rp_env == 2 || rp_env == 4 ? rp_env : 1);      // measured equal within the noise (profiles/r03_k1_dma_rows_per_tile.txt): 1
   A.B = B; A.H = H; A.W = W;
   A.tiles_x = (W + DW - 1) / DW;
   A.tiles_y = (H + p.nw * p.rp - 1) / (p.nw * p.rp);
@@ -380,13 +389,13 @@ Plan make_plan(int B, int H, int W, bool bwd, DmaArgs& A) {
   return p;
 }
 
-template <int OC, bool BWD, int NW, bool NTL, int RP>
+template <int OC, bool BWD, int NW, bool NTL, int RP, bool SIG = false>
 void launch4(const Plan& p, const DmaArgs& A, hipStream_t s) {
   const dim3 grid(p.grid);
   if constexpr (RP == 1) {
-    if (p.split) { hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, true, 1>), grid, dim3(2 * NW * 64), 0, s, A); return; }
+    if (p.split) { hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, true, 1, SIG>), grid, dim3(2 * NW * 64), 0, s, A); return; }
   }
-  hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, false, RP>), grid, dim3(NW * 64), 0, s, A);
+  hipLaunchKernelGGL((prop_dma_kernel<OC, NW, BWD, NTL, false, RP, SIG>), grid, dim3(NW * 64), 0, s, A);
 }
 
 template <int OC, bool BWD, bool NTL>
@@ -424,6 +433,7 @@ int prop_dma_forward(const float* dem, const float* weight, const float* offset,
                      float scale, float* out, int B, int H, int W, hipStream_t s) {
   DmaArgs A{};
   A.dem = dem; A.weight = weight; A.offset = offset; A.wk = wk; A.b0 = b0; A.out = out; A.scale = scale;
+  A.wbs = (size_t)9 * H * W; A.obs = (size_t)oc * H * W;
   const Plan p = make_plan(B, H, W, false, A);
   if (oc == 18) launch<18, false>(p, A, s); else launch<16, false>(p, A, s);
   return check_launch("prop_forward (dma)");
@@ -434,9 +444,33 @@ int prop_dma_backward(const float* gout, const float* dem, const float* weight, 
   DmaArgs A{};
   A.dem = dem; A.weight = weight; A.offset = offset; A.gout = gout; A.wk = wk; A.gweight = gweight; A.goffset = goffset;
   A.partial = partial;
+  A.wbs = (size_t)9 * H * W; A.obs = (size_t)oc * H * W;
   const Plan p = make_plan(B, H, W, true, A);
   if (oc == 18) launch<18, true>(p, A, s); else launch<16, true>(p, A, s);
   return check_launch("prop_backward (dma)");
+}
+
+// The in-model form: ONE (B,25,H,W) fp32 tensor, planes 0..8 affinity LOGITS, 9..24 the sixteen learned offsets -- the
+// generator head's output as jspsr_head_forward writes it; the gradient in the same layout.  Same kernel, SIG = true.
+int prop_dma_logits_forward(const float* dem, const float* head, const float* wk, const float* b0, float scale, float* out,
+                            int B, int H, int W, hipStream_t s) {
+  DmaArgs A{};
+  A.dem = dem; A.weight = head; A.offset = head + (size_t)9 * H * W; A.wk = wk; A.b0 = b0; A.out = out; A.scale = scale;
+  A.wbs = A.obs = (size_t)25 * H * W;
+  const Plan p = make_plan(B, H, W, false, A, false);
+  if (p.ntl) launch4<16, false, 4, true, 1, true>(p, A, s); else launch4<16, false, 4, false, 1, true>(p, A, s);
+  return check_launch("prop_logits_forward (dma)");
+}
+
+int prop_dma_logits_backward(const float* gout, const float* dem, const float* head, const float* wk, float* ghead, float* partial,
+                             int B, int H, int W, hipStream_t s) {
+  DmaArgs A{};
+  A.dem = dem; A.weight = head; A.offset = head + (size_t)9 * H * W; A.gout = gout; A.wk = wk;
+  A.gweight = ghead; A.goffset = ghead + (size_t)9 * H * W; A.partial = partial;
+  A.wbs = A.obs = (size_t)25 * H * W;
+  const Plan p = make_plan(B, H, W, true, A, false);
+  if (p.ntl) launch4<16, true, 4, true, 1, true>(p, A, s); else launch4<16, true, 4, false, 1, true>(p, A, s);
+  return check_launch("prop_logits_backward (dma)");
 }
 
 }  // namespace jspsr

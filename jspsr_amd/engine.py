@@ -8,6 +8,8 @@ layouts, so the DEM and the output need no conversion.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -159,6 +161,30 @@ def channel_gate(x, w1, w2):
 def propagate_head(dem, head, w, b, scale=1.0):
     """K1h: sigmoid + propagation straight from the merged 1x1 head's NHWC output (ops.propagate_head)."""
     return ops.propagate_head(dem.contiguous(), head, w, b, scale)
+
+
+# JSPSR_HEAD_PLANES=0: the models feed the propagation step from the 32-channel NHWC head again (K1h / K1hd, rounds 2-3)
+planar_heads = os.environ.get("JSPSR_HEAD_PLANES", "1") != "0"
+
+
+def heads_propagate(dem, feature, conv_weight, conv_offset, w, b, scale=1.0):
+    """The two 1x1 heads (spn.py:66-68; LRRU.py:238-247) + Sigmoid + zero centre offset + PostProcessor.forward
+    (spn.py:43,69-73,99-118) as the models run them.  dem (B,1,H,W) fp32 detached, feature NHWC in the compute dtype,
+    conv_weight / conv_offset the reference-named nn.Conv2d modules (9 and 16 rows).
+    Round 4: the heads write the (B,25,H,W) fp32 planes the propagation kernel of the PUBLIC boundary reads (K1c,
+    ops.head_planes -> ops.propagate_logits): the in-model step is the roofline kernel itself, nothing is padded or
+    transposed, and the learned offsets / affinity logits stay fp32 whatever the storage type of the network."""
+    dem = dem.contiguous()
+    if planar_heads and ops.head_planes_ok(feature):
+        planes = ops.head_planes(feature, conv_weight.weight, conv_weight.bias, conv_offset.weight, conv_offset.bias)
+        if _offset_probe is not None:
+            _offset_probe.append(planes[:, 9:].permute(0, 2, 3, 1))
+        return ops.propagate_logits(dem, planes, w, b, scale)
+    w_all, b_all = ops.merge_heads(conv_weight.weight, conv_weight.bias, conv_offset.weight, conv_offset.bias)
+    head = conv2d(feature, w_all, b_all)
+    if _offset_probe is not None:
+        _offset_probe.append(ops.split_head(head)[1])
+    return ops.propagate_head(dem, head, w, b, scale)
 
 
 def cat(tensors):

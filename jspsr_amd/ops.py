@@ -344,6 +344,107 @@ def propagate_head(dem, head, w, b, scale: float = 1.0):
     return _PropagateHead.apply(dem, head, w, b, scale)
 
 
+# ---- K1c + K1 in the models (round 4): the heads write PLANES, the propagation step reads them -------------------------
+HEAD_PLANES = 25          # 9 affinity logits + 16 learned offsets (Generator's order: spn.py:41-52,66-68)
+
+
+def head_planes_ok(x) -> bool:
+    """Can the planar head route take this feature tensor?  (H*W a multiple of 32, 32 / 64 / 128 channels, fp32 | bf16.)"""
+    if not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    B, H, W, C = x.shape
+    return bool(_lib.load().jspsr_head_ok(K._dt(x), B, H, W, C))
+
+
+class _HeadPlanes(torch.autograd.Function):
+    """The two 1x1 heads of Generator.forward (spn.py:66-68, without the Sigmoid) as ONE convolution writing the
+    (B,25,H,W) fp32 operand of the propagation step: jspsr_head_forward; backward = jspsr_head_backward (data gradient,
+    bias gradient, and the NHWC copy of the gradient the weight-gradient kernel reads) + jspsr_conv2d_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w25, b25):
+        x = K.nhwc(x)
+        B, H, W, C = x.shape
+        w = w25.detach().reshape(HEAD_PLANES, C).contiguous().float()
+        b = b25.detach().contiguous().float()
+        planes = torch.empty((B, HEAD_PLANES, H, W), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        _lib.check(lib.jspsr_head_forward(K._dt(x), x.data_ptr(), K.pitch(x), 0, C, w.data_ptr(), b.data_ptr(), planes.data_ptr(),
+                                          B, H, W, _stream()), "jspsr_head_forward")
+        ctx.save_for_backward(x, w)
+        return planes
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B, H, W, C = x.shape
+        g = g.contiguous()
+        lib = _lib.load()
+        dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device) if ctx.needs_input_grad[0] else None
+        gn = torch.empty((B, H, W, 32), dtype=x.dtype, device=x.device)
+        db = torch.empty(HEAD_PLANES, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.jspsr_head_backward_workspace_bytes(B, H, W), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.jspsr_head_backward(K._dt(x), g.data_ptr(), w.data_ptr(), C, dx.data_ptr() if dx is not None else None,
+                                           C, 0, gn.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, W, _stream()),
+                   "jspsr_head_backward")
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = _wgrad_async(None, gn, x, 32, C, 1, 1, 1, 0)[:HEAD_PLANES]
+        return dx, dW, db if ctx.needs_input_grad[2] else None
+
+
+def head_planes(x, w_weight, b_weight, w_offset, b_offset):
+    """(B,H,W,C) NHWC feature -> (B,25,H,W) fp32 planes [9 affinity logits | 16 offsets]; differentiable with respect to
+    the feature and the two reference-named heads' parameters."""
+    w25 = torch.cat((w_weight, w_offset), 0)
+    b25 = torch.cat((b_weight, b_offset), 0)
+    return _HeadPlanes.apply(x, w25, b25)
+
+
+class _PropagateLogits(torch.autograd.Function):
+    """Sigmoid (spn.py:43) + zero centre offset (spn.py:69-73) + PostProcessor.forward (spn.py:99-118) on the planar
+    head: jspsr_prop_logits_forward_f32 / _backward_f32 -- the kernels of the public PostProcessor boundary."""
+
+    @staticmethod
+    def forward(ctx, dem, head, w, b, scale):
+        _need_gpu(dem, head, w, b)
+        B, one, H, W = dem.shape
+        if one != 1 or tuple(head.shape) != (B, HEAD_PLANES, H, W) or head.dtype != torch.float32:
+            raise ValueError(f"propagate_logits: dem {tuple(dem.shape)} against head {tuple(head.shape)} {head.dtype} (want fp32 (B,{HEAD_PLANES},H,W))")
+        if w.numel() != 9 or b.numel() != 1:
+            raise ValueError("propagate_logits: w must have 9 elements and b 1")
+        dem, head, w, b = dem.contiguous(), head.contiguous(), w.contiguous(), b.contiguous()
+        out = torch.empty_like(dem)
+        lib = _lib.load()
+        _lib.check(lib.jspsr_prop_logits_forward_f32(dem.data_ptr(), head.data_ptr(), w.data_ptr(), b.data_ptr(), float(scale),
+                                                     out.data_ptr(), B, H, W, _stream()), "jspsr_prop_logits_forward_f32")
+        ctx.save_for_backward(dem, head, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dem, head, w = ctx.saved_tensors
+        B, _, H, W = dem.shape
+        grad_out = grad_out.contiguous()
+        ghead = torch.empty_like(head)
+        gw = torch.empty_like(w)
+        gb = torch.empty(1, device=dem.device, dtype=dem.dtype)
+        lib = _lib.load()
+        ws = torch.empty(max(lib.jspsr_prop_backward_workspace_bytes(B, H, W), 16), dtype=torch.uint8, device=dem.device)
+        _lib.check(lib.jspsr_prop_logits_backward_f32(grad_out.data_ptr(), dem.data_ptr(), head.data_ptr(), w.data_ptr(),
+                                                      ghead.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), B, H, W,
+                                                      _stream()), "jspsr_prop_logits_backward_f32")
+        return None, ghead, gw, gb, None
+
+
+def propagate_logits(dem, head, w, b, scale: float = 1.0):
+    """out = b + sum_k w_k (a_k - mean a) bilinear(dem, p_k + offset_k) + scale*dem, a = sigmoid(head[:, :9]), offsets
+    head[:, 9:] (the eight learned taps; the centre tap's offset is zero).  dem (B,1,H,W) fp32, head (B,25,H,W) fp32."""
+    if dem.requires_grad:
+        raise RuntimeError("propagate_logits: dem must be detached (no gradient with respect to the DEM is produced)")
+    return _PropagateLogits.apply(dem, head, w, b, scale)
+
+
 # =============================================================================================
 # NHWC layer operators: torch.autograd.Function shells around jspsr_amd.kernels (HIP).
 # Tensors are (B, H, W, C) contiguous, fp32 or bf16; parameters stay fp32 masters.

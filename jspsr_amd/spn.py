@@ -88,6 +88,10 @@ class PostProcessor(nn.Module):
         """offset: (B,18,H,W) torchvision layout, or (B,16,H,W) without the zero centre pair."""
         return E.propagate(init_dem, weight, offset, self.w, self.b, self.scale)
 
+    def from_feature(self, init_dem, feature, generator):
+        """Inside the models: the generator's last feature -> heads -> propagation (engine.heads_propagate)."""
+        return E.heads_propagate(init_dem, feature, generator.conv_weight[0], generator.conv_offset.conv[0], self.w, self.b, self.scale)
+
     def from_head(self, init_dem, head):
         """Inside the models: the merged head's NHWC output (Generator.head) goes straight into the kernel."""
         return E.propagate_head(init_dem, head, self.w, self.b, self.scale)
