@@ -114,19 +114,66 @@ def time_k1(model, inputs, iters=20):
     res, reps = {}, {}
     for name, fn in (("fwd", fwd), ("bwd", bwd), ("bwd_call", bwd_call)):
         res[name], reps[name] = timed(fn)
+    # The step AS THE MODELS LAUNCH IT (round 4): the generator's heads write one (B,25,H,W) fp32 tensor -- 9 affinity
+    # LOGITS + 16 offsets -- and jspsr_prop_logits_* runs the same persistent LDS-DMA kernel with the sigmoid folded in
+    # (SIG = true): same operands, same 108 / 208 algorithmic bytes per pixel as the public boundary, nothing padded.
+    from jspsr_amd import _lib, kernels as K
+    lib = _lib.load()
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    lsets = [torch.cat((1.5 * torch.randn(B, 9, H, W, device=dev, generator=g), 1.5 * torch.randn(B, 16, H, W, device=dev, generator=g)), 1)
+             for _ in range(nset)]
+    glsets = [torch.empty_like(t) for t in lsets]
+
+    def lfwd(i):
+        _lib.check(lib.jspsr_prop_logits_forward_f32(dem.data_ptr(), lsets[i % nset].data_ptr(), w.data_ptr(), b.data_ptr(), 1.0,
+                                                     out.data_ptr(), B, H, W, st()), "jspsr_prop_logits_forward_f32")
+
+    def lbwd(i):
+        _lib.check(lib.jspsr_prop_logits_backward_f32(gout.data_ptr(), dem.data_ptr(), lsets[i % nset].data_ptr(), w.data_ptr(),
+                                                      glsets[i % nset].data_ptr(), None, None, ws.data_ptr(), B, H, W, st()),
+                   "jspsr_prop_logits_backward_f32")
+
+    census = lambda n: lib.jspsr_launch_count(n.encode())
+    c0 = (census("prop_logits_forward (dma)"), census("prop_logits_backward (dma)"))
+    for name, fn in (("lfwd", lfwd), ("lbwd", lbwd)):
+        res[name], reps[name] = timed(fn)
+    # the names reported below are the kernels this process launched: the launch census must have moved
+    logits_dma = (census("prop_logits_forward (dma)") - c0[0] == 3 * (300 + iters) and
+                  census("prop_logits_backward (dma)") - c0[1] == 3 * (300 + iters))
+    del lsets, glsets
+    # K1c: the heads themselves (csrc/head.hip) on the generator's 128-channel feature in the model's storage dtype
+    hdt = model.compute_dtype
+    es = 2 if hdt == torch.bfloat16 else 4
+    cin = model.generator.conv_weight[0].in_channels
+    nx = max(2, int(700e6 // (B * H * W * cin * es)) + 1)
+    xs = [torch.randn(B, H, W, cin, device=dev, generator=g).to(hdt) for _ in range(nx)]
+    dxs = [torch.empty_like(t) for t in xs[:2]]
+    w25 = (0.1 * torch.randn(25, cin, device=dev, generator=g)).contiguous()
+    b25 = torch.zeros(25, device=dev)
+    planes = [torch.randn(B, 25, H, W, device=dev, generator=g) for _ in range(2)]
+    gn = torch.empty(B, H, W, 32, device=dev, dtype=hdt)
+    db = torch.empty(25, device=dev)
+    cws = torch.empty(lib.jspsr_head_backward_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
+
+    def cfwd(i):
+        _lib.check(lib.jspsr_head_forward(K._dt(xs[0]), xs[i % nx].data_ptr(), cin, 0, cin, w25.data_ptr(), b25.data_ptr(),
+                                          planes[i % 2].data_ptr(), B, H, W, st()), "jspsr_head_forward")
+
+    def cbwd(i):
+        _lib.check(lib.jspsr_head_backward(K._dt(xs[0]), planes[i % 2].data_ptr(), w25.data_ptr(), cin, dxs[i % 2].data_ptr(), cin, 0,
+                                           gn.data_ptr(), db.data_ptr(), cws.data_ptr(), B, H, W, st()), "jspsr_head_backward")
+
+    for name, fn in (("cfwd", cfwd), ("cbwd", cbwd)):
+        res[name], reps[name] = timed(fn, 1, 50)
+    del xs, dxs, planes, gn
     # K1h: the entry the model itself uses (operands straight from the merged head's 32-channel NHWC output, in the
     # model's storage dtype): same timing rules.  Two byte counts per launch: `moved` = what the layout makes the kernel
     # touch (32 channels, 7 of them padding / the centre logit), `algorithmic` = the 25 operand elements + dem + out
     # (+ their gradients) of SURVEY 8d in that dtype.
-    from jspsr_amd import _lib, kernels as K
-    lib = _lib.load()
-    hdt = model.compute_dtype
-    es = 2 if hdt == torch.bfloat16 else 4
     nh = max(2, int(700e6 // (B * H * W * 32 * es)) + 1)
     heads = [(1.5 * torch.randn(B, H, W, 32, device=dev, generator=g)).to(hdt) for _ in range(nh)]
     gheads = [torch.empty_like(h) for h in heads]
     hws = torch.empty(max(lib.jspsr_prop_head_backward_workspace_bytes(B, H, W), 16), dtype=torch.uint8, device=dev)
-    st = lambda: torch.cuda.current_stream().cuda_stream
 
     def hfwd(i):
         _lib.check(lib.jspsr_prop_head_forward(K._dt(heads[0]), dem.data_ptr(), heads[i % nh].data_ptr(), w.data_ptr(),
@@ -138,7 +185,8 @@ def time_k1(model, inputs, iters=20):
                                                 B, H, W, st()), "jspsr_prop_head_backward")
 
     for name, fn in (("hfwd", hfwd), ("hbwd", hbwd)):
-        res[name], reps[name] = timed(fn)
+        res[name], reps[name] = timed(fn, 1, 100)
+    del heads, gheads
     # K1s: the general step of N-iteration chains (NLSPN, models/components/nlspn.py:177-233): raw affinities, gradients
     # ADDED into the shared affinity / offset gradients, and the gradient with respect to the raster (LDS scatter + float
     # atomics).  One step each way; algorithmic bytes = K1's + 4 B/px of grad_dem (+ the read of the accumulators).
@@ -165,56 +213,61 @@ def time_k1(model, inputs, iters=20):
         "note": "one propagation step of an N-iteration chain (NLSPN): forward 108 B/px; backward with accumulate = 1 reads "
                 "the 25 gradient planes it adds into (100 B/px) and adds grad_dem by float atomics (4 B/px each way) on top of K1's 208",
     }
-    head = {
-        "kernel": (traffic_names.get("head_bf16_fwd_kernel", "prop_head_dma_kernel<4, false, true>") + " / " +
-                   traffic_names.get("head_bf16_bwd_kernel", "prop_head_dma_kernel<4, true, true>")) if es == 2 else "prop_head_kernel<float, false|true>",
+    split_env = os.environ.get("JSPSR_PROP_SPLIT")
+    form = lambda bwd: ("false" if split_env == "0" else "true") if split_env is not None else ("false" if bwd else "true")   # defaults: forward split, backward symmetric
+    ntl = "false" if os.environ.get("JSPSR_PROP_NTL") == "0" else "true"
+    # prop_dma_kernel<OC, NW, BWD, NTL, SPLIT, RP, SIG> (csrc/prop_dma.hip); the logits entry takes 4-wave one-row tiles only
+    kname = lambda bwd, sig: "prop_dma_kernel<16, 4, %s, %s, %s, 1, %s>" % ("true" if bwd else "false", ntl, form(bwd), "true" if sig else "false")
+    traffic = traffic_names or None
+    tr = lambda key: traffic.get(key) if traffic else None
+    # 16-channel offset layout (the all-zero centre pair is not stored): 108 B/px fwd, 208 B/px bwd -- SURVEY 8d
+    fb, bb = 108.0 * px, 208.0 * px
+    gbs = lambda nbytes, t: round(nbytes / t / 1e9, 1)
+    frac = lambda nbytes, t: round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4)
+    legacy = {
+        "kernel": "prop_head_dma_kernel<4, BWD, SPLIT>" if es == 2 else "prop_head_kernel<float, BWD>",
         "dtype": "bf16" if es == 2 else "f32",
         "fwd_us": round(res["hfwd"] * 1e6, 2), "bwd_us": round(res["hbwd"] * 1e6, 2),
-        "fwd_moved_GBs": round((32 * es + 8.0) * px / res["hfwd"] / 1e9, 1), "bwd_moved_GBs": round((64 * es + 8.0) * px / res["hbwd"] / 1e9, 1),
-        "fwd_algorithmic_GBs": round((25 * es + 8.0) * px / res["hfwd"] / 1e9, 1),
-        "bwd_algorithmic_GBs": round((50 * es + 8.0) * px / res["hbwd"] / 1e9, 1),
-        "note": "the in-model entry: replaces sigmoid + two NHWC->planar transposes + planar K1 (+ their backward passes) by one "
-                "launch each way; bytes per pixel moved: 32*es + 8 fwd, 64*es + 8 bwd",
+        "fwd_moved_GBs": gbs((32 * es + 8.0) * px, res["hfwd"]), "bwd_moved_GBs": gbs((64 * es + 8.0) * px, res["hbwd"]),
+        "fwd_algorithmic_GBs": gbs((25 * es + 8.0) * px, res["hfwd"]), "bwd_algorithmic_GBs": gbs((50 * es + 8.0) * px, res["hbwd"]),
+        "note": "rounds 2-3's in-model entry (operands from a 32-channel NHWC head, 7 channels of it padding); JSPSR_HEAD_PLANES=0 "
+                "selects it, and shapes jspsr_head_ok() refuses still take it",
     }
-    # 16-channel offset layout (the all-zero centre pair is not stored): 108 B/px fwd, 208 B/px bwd
-    fb, bb = 108.0 * px, 208.0 * px
-    bw_f, bw_b = fb / res["fwd"] / 1e9, bb / res["bwd"] / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "k1_pmc.json")
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc))
-    in_model = {
-        "kernel": head["kernel"], "dtype": head["dtype"],
-        "note": "what the benchmarked step launches for spn.py:99-118 (K1h: operands straight from the merged head's NHWC "
-                "output); algorithmic = (25 operand elements (+ 25 gradients) in the storage dtype + fp32 dem + fp32 out / "
-                "grad_out) per pixel, moved = the 32-channel layout's bytes",
-        "forward": {"us_per_launch": head["fwd_us"], "achieved": head["fwd_algorithmic_GBs"],
-                    "frac": round(head["fwd_algorithmic_GBs"] / HBM_PEAK_GBS, 4),
-                    "moved_GBs": head["fwd_moved_GBs"], "moved_frac": round(head["fwd_moved_GBs"] / HBM_PEAK_GBS, 4),
-                    "traffic": traffic.get(f"head_{head['dtype']}_fwd_bytes_per_launch") if traffic else None},
-        "backward": {"us_per_launch": head["bwd_us"], "achieved": head["bwd_algorithmic_GBs"],
-                     "frac": round(head["bwd_algorithmic_GBs"] / HBM_PEAK_GBS, 4),
-                     "moved_GBs": head["bwd_moved_GBs"], "moved_frac": round(head["bwd_moved_GBs"] / HBM_PEAK_GBS, 4),
-                     "traffic": traffic.get(f"head_{head['dtype']}_bwd_bytes_per_launch") if traffic else None},
+    xb = cin * es
+    head_conv = {
+        "kernel": "head_fwd_kernel / head_bwd_kernel<%s, %d> (K1c, csrc/head.hip)" % ("__bf16" if es == 2 else "float", cin),
+        "fwd_us": round(res["cfwd"] * 1e6, 2), "bwd_us": round(res["cbwd"] * 1e6, 2),
+        "fwd_GBs": gbs((xb + 100.0) * px, res["cfwd"]), "bwd_GBs": gbs((100.0 + xb + 32 * es) * px, res["cbwd"]),
+        "note": "the two 1x1 heads as one conv writing the 25 fp32 planes (forward: reads the feature, writes 100 B/px; backward: "
+                "reads the 25 gradient planes, writes the feature's gradient and the 32-channel NHWC copy the weight-gradient kernel reads)",
     }
-    kname = lambda d: (traffic or {}).get(f"{d}_kernel", "prop_dma_kernel<16, 4, %s, true, %s>" % (("false", "true") if d == "fwd" else ("true", "false")))
+    public = {
+        "kernel": kname(True, False), "achieved": gbs(bb, res["bwd"]), "frac": frac(bb, res["bwd"]),
+        "traffic": tr("bwd_bytes_per_launch"), "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2),
+        "us_per_launch_reps": reps["bwd"], "us_per_call_with_fold": round(res["bwd_call"] * 1e6, 2),
+        "forward": {"kernel": kname(False, False), "achieved": gbs(fb, res["fwd"]), "frac": frac(fb, res["fwd"]),
+                    "traffic": tr("fwd_bytes_per_launch"), "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2),
+                    "us_per_launch_reps": reps["fwd"]},
+        "note": "PostProcessor.forward's own boundary (jspsr_prop_forward_f32 / _backward_f32: affinities after the sigmoid, two tensors)",
+    }
     return {
-        "bound": "hbm", "kernel": kname("bwd"), "achieved": round(bw_b, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bw_b / HBM_PEAK_GBS, 4),
-        "traffic": traffic.get("bwd_bytes_per_launch") if traffic else None,
-        "bytes_per_launch": bb, "us_per_launch": round(res["bwd"] * 1e6, 2), "us_per_launch_reps": reps["bwd"],
-        "us_per_call_with_fold": round(res["bwd_call"] * 1e6, 2),
-        "forward": {"kernel": kname("fwd"), "achieved": round(bw_f, 1), "frac": round(bw_f / HBM_PEAK_GBS, 4),
-                    "traffic": traffic.get("fwd_bytes_per_launch") if traffic else None,
-                    "bytes_per_launch": fb, "us_per_launch": round(res["fwd"] * 1e6, 2), "us_per_launch_reps": reps["fwd"]},
-        "kernel_in_model": in_model["kernel"], "in_model": in_model,
-        "head_entry": head,
-        "steps_entry": steps_entry,
-        "note": "the PostProcessor.forward boundary (planar fp32 operands, the public operator: spn.py:99-118) on the persistent "
-                "LDS-DMA kernels of csrc/prop_dma.hip; in_model = the same step as the models launch it; algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / "
-                "mean launch duration (events on the launch stream, back-to-back launches of that kernel alone; "
-                "us_per_call_with_fold adds the 10-workgroup fold launch of the backward C-ABI call); traffic = PMC "
-                "FETCH_SIZE+WRITE_SIZE per launch from profiles/k1_pmc.json (separate rocprofv3 --pmc passes)",
+        "bound": "hbm", "kernel": kname(True, True) if logits_dma else "prop_bwd_kernel<16, 1, true, 8, 64, true>",
+        "achieved": gbs(bb, res["lbwd"]), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(bb, res["lbwd"]),
+        "traffic": tr("logits_bwd_bytes_per_launch"),
+        "bytes_per_launch": bb, "us_per_launch": round(res["lbwd"] * 1e6, 2), "us_per_launch_reps": reps["lbwd"],
+        "forward": {"kernel": kname(False, True) if logits_dma else "prop_fwd_kernel<16, 1, true, 8, 64, true>",
+                    "achieved": gbs(fb, res["lfwd"]), "frac": frac(fb, res["lfwd"]),
+                    "traffic": tr("logits_fwd_bytes_per_launch"), "bytes_per_launch": fb,
+                    "us_per_launch": round(res["lfwd"] * 1e6, 2), "us_per_launch_reps": reps["lfwd"]},
+        "kernel_in_model": True, "launch_census_checked": bool(logits_dma),
+        "public_boundary": public, "head_conv": head_conv, "legacy_nhwc_head": legacy, "steps_entry": steps_entry,
+        "note": "top level = the propagation kernel THE BENCHMARKED STEP LAUNCHES for spn.py:43,69-73,99-118 (jspsr_prop_logits_*: "
+                "planar fp32 logits + offsets written by the generator's heads, sigmoid inside; backward in the top-level keys, "
+                "forward beside it); public_boundary = the same kernel template at PostProcessor.forward's own signature. "
+                "achieved = algorithmic bytes (SURVEY 8d with 16-ch offsets: 108 / 208 B per pixel) x pixels per launch / mean "
+                "launch duration (events on the launch stream, back-to-back launches of that kernel alone behind 300 warm-up "
+                "launches; median of three 20-launch blocks); traffic = PMC FETCH_SIZE + WRITE_SIZE per launch from "
+                "profiles/k1_pmc.json (separate rocprofv3 --pmc passes, FETCH_SIZE doubled per the guide)",
     }
 
 

@@ -5,9 +5,11 @@
 # instruction other than our own `s_mov_b32 m0, sN` + the DMA that follows reads or writes it.
 set -e
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+# the flags the product objects are built with (csrc/Makefile passes its FLAGS; lab builds pass theirs incl. their -D switches)
+M0_FLAGS=${M0_FLAGS:---offload-arch=gfx950 -O3 -std=c++17}
 for src in "$@"; do
   asm=$(mktemp /tmp/m0check.XXXXXX.s)
-  $HIPCC --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S "$src" -o "$asm"
+  $HIPCC $M0_FLAGS --cuda-device-only -S "$src" -o "$asm"
   bad=$(grep -nw "m0" "$asm" | grep -v "^\S*\s*;" | grep -v "s_mov_b32 m0, s[0-9]*$" || true)
   n=$(grep -c "s_mov_b32 m0, s" "$asm" || true)
   rm -f "$asm"

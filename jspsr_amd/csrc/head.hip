@@ -57,6 +57,31 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
+// A wave-private LDS image of 32 pixel rows x NC 16-byte chunks, XOR-swizzled so that both access shapes are conflict-free
+// (a ds_*_b128 lane group of 16 lanes must cover 16 distinct 16-byte slots of the 256-byte bank window):
+//   written   "column-wise": lane (p, h) holds chunks of ITS pixel -- 16 consecutive lanes = 16 pixels, one chunk index;
+//   read back "row-wise":    lane l = chunk l % NC of pixel l / NC -- consecutive lanes = consecutive bytes of the NHWC
+//                            tensor, so a wave store instruction writes 1 KiB contiguous instead of 64 scattered 16-byte
+//                            pieces (which cost the L2 eight write requests per line: 345 -> 2xx us on the backward).
+template <int NC>
+struct RowTile {
+  static_assert(NC == 4 || NC == 8 || NC == 16 || NC == 32, "chunks per pixel row");
+  static constexpr int BYTES = 32 * NC * 16;
+  static __device__ __forceinline__ int off(int p, int c) {
+    const int sw = NC >= 16 ? (p & 15) : ((p >> (NC == 8 ? 1 : 2)) & (NC - 1));
+    return (p * NC + ((c & ~15) | ((c & 15) ^ sw))) * 16;
+  }
+  // store the image to `base` (+ q * pitch_bytes per pixel row q): NC / 2 wave instructions
+  static __device__ __forceinline__ void flush(const char* img, char* base, size_t pitch_bytes, int lane) {
+#pragma unroll
+    for (int i = 0; i < NC / 2; ++i) {
+      const int q = i * (64 / NC) + lane / NC, c = lane % NC;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + off(q, c));
+      *reinterpret_cast<u32x4*>(base + (size_t)q * pitch_bytes + c * 16) = v;
+    }
+  }
+};
+
 // ---- forward ----------------------------------------------------------------------------------------------------------
 template <typename T, int CIN>
 __global__ __launch_bounds__(WPB * 64) void head_fwd_kernel(const HeadArgs A) {
@@ -141,6 +166,12 @@ __global__ __launch_bounds__(WPB * 64) void head_bwd_kernel(const HeadArgs A) {
   const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const long long wave0 = (long long)blockIdx.x * WPB + wave, nwaves = (long long)gridDim.x * WPB;
   __shared__ float red[WPB][32];
+  constexpr int ES = BF ? 2 : 4;
+  using DxTile = RowTile<CIN * ES / 16>;       // the data gradient's 32 pixel rows
+  using GnTile = RowTile<32 * ES / 16>;        // the 32-channel NHWC copy's
+  __shared__ __attribute__((aligned(16))) char tiles[WPB][(DX ? DxTile::BYTES : 0) + GnTile::BYTES];
+  char* const gn_img = tiles[wave];
+  char* const dx_img = tiles[wave] + GnTile::BYTES;
 
   // plane of this lane's value v (bf16: v = 8 s + i -> n = 16 s + 8 h + i; fp32: n = 16 h + v): see the file header
   auto plane_of = [&](int v) { return BF ? 16 * (v >> 3) + 8 * h + (v & 7) : 16 * h + v; };
@@ -189,7 +220,8 @@ __global__ __launch_bounds__(WPB * 64) void head_bwd_kernel(const HeadArgs A) {
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) bsum[v] += gv[v];
-    T* gnp = reinterpret_cast<T*>(A.gn) + (size_t)(gp0 + p) * 32;
+    // results go through the wave's LDS images (column-wise in, row-wise out: RowTile) and leave as contiguous rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous group's flush has read the images (wave-private: program order)
     if constexpr (BF) {
       bf16x8 gb[2];
 #pragma unroll
@@ -198,10 +230,9 @@ __global__ __launch_bounds__(WPB * 64) void head_bwd_kernel(const HeadArgs A) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = gv[8 * s + i];
         gb[s] = pack8(f);
-        *reinterpret_cast<bf16x8*>(gnp + 16 * s + 8 * h) = gb[s];
+        *reinterpret_cast<bf16x8*>(gn_img + GnTile::off(p, 2 * s + h)) = gb[s];       // channels 16 s + 8 h ..
       }
       if constexpr (DX) {
-        T* dxp = reinterpret_cast<T*>(A.dx) + (size_t)(gp0 + p) * A.dx_cs + A.dx_coff + h * (CIN / 2);
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
           f32x16 acc;
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(WPB * 64) void head_bwd_kernel(const HeadArgs A) {
           for (int q = 0; q < 2; ++q) {
             const u32x4 o = {pack2(acc[8 * q + 0], acc[8 * q + 1]), pack2(acc[8 * q + 2], acc[8 * q + 3]),
                              pack2(acc[8 * q + 4], acc[8 * q + 5]), pack2(acc[8 * q + 6], acc[8 * q + 7])};
-            *reinterpret_cast<u32x4*>(dxp + 16 * t + 8 * q) = o;
+            *reinterpret_cast<u32x4*>(dx_img + DxTile::off(p, h * (CIN / 16) + 2 * t + q)) = o;    // channels h CIN/2 + 16 t + 8 q ..
           }
         }
       }
@@ -221,10 +252,9 @@ __global__ __launch_bounds__(WPB * 64) void head_bwd_kernel(const HeadArgs A) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 o = {gv[4 * q], gv[4 * q + 1], gv[4 * q + 2], gv[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(gnp + 16 * h + 4 * q) = o;
+        *reinterpret_cast<f32x4*>(gn_img + GnTile::off(p, 4 * h + q)) = o;              // channels 16 h + 4 q ..
       }
       if constexpr (DX) {
-        T* dxp = reinterpret_cast<T*>(A.dx) + (size_t)(gp0 + p) * A.dx_cs + A.dx_coff + h * (CIN / 2);
 #pragma unroll
         for (int t = 0; t < NTL; ++t) {
           f32x16 acc;
@@ -235,11 +265,15 @@ __global__ __launch_bounds__(WPB * 64) void head_bwd_kernel(const HeadArgs A) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 o = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(dxp + 16 * t + 4 * q) = o;
+            *reinterpret_cast<f32x4*>(dx_img + DxTile::off(p, h * (CIN / 8) + 4 * t + q)) = o;     // channels h CIN/2 + 16 t + 4 q ..
           }
         }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the images are complete (the LDS operations of one wave complete in order)
+    GnTile::flush(gn_img, reinterpret_cast<char*>(A.gn) + (size_t)gp0 * 32 * ES, (size_t)32 * ES, lane);
+    if constexpr (DX)
+      DxTile::flush(dx_img, reinterpret_cast<char*>(A.dx) + ((size_t)gp0 * A.dx_cs + A.dx_coff) * ES, (size_t)A.dx_cs * ES, lane);
   }
 
   // per-plane sums of this workgroup: lanes of one half hold the same 16 planes

@@ -157,7 +157,10 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
 
     const int y0 = ty * NW, x0 = tx * DW;
     const int y = y0 + wave, x = x0 + lane;
-    counted = y < H;
+    // the counted wait above assumes EVERY one of the row's NST stores was issued: in the backward a store piece whose 16
+    // pixels all lie beyond W has no active lane and is skipped (execz), so a ragged last column tile (W - x0 < 64) waits
+    // for everything instead (vmcnt(4) could otherwise return with the next tile's pieces still in flight)
+    counted = y < H && (!BWD || x0 + DW <= W);
     if (computes && y < H) {
       char* ob = smem + 2 * C::DEMB + (buf * NW + wave) * HOPB;
       const int sw = (lane >> 2) & 3;                      // this pixel's chunk c lives in slot c ^ sw

@@ -33,6 +33,7 @@ class FlatAdamW:
         off = 0
         self._slices = {}                            # id(parameter) -> (offset, numel) in the flat buffers
         self._over = over
+        self._group_of = {}                          # id(parameter) -> its entry of param_groups
         for p in reversed(reducer.params):          # same order as the gradient buffer
             n = p.numel()
             self._slices[id(p)] = (off, n)
@@ -45,6 +46,9 @@ class FlatAdamW:
                     self.param_groups.append(g)
             else:
                 g = self.param_groups[0]
+            # membership is recorded HERE, by identity -- not re-derived later from the groups' mutable "lr" / "initial_lr"
+            # (a scheduler step or a loaded checkpoint rewrites those: ADVICE r3)
+            self._group_of[id(p)] = g
             if g["ranges"] and g["ranges"][-1][1] == off:
                 g["ranges"][-1][1] = off + n
             else:
@@ -88,11 +92,7 @@ class FlatAdamW:
     def _torch_order(self):
         """The parameters in the order torch.optim.AdamW numbers them when built as the reference builds it
         (utils/common_config.py:241-258): model.parameters() order, the `diff_lr` parameters moved to a second group."""
-        plain = [p for p in self.reducer.params if id(p) not in self._over]
-        groups = [plain]
-        for g in self.param_groups[1:]:
-            groups.append([p for p in self.reducer.params if self._over.get(id(p)) == g["initial_lr"] or self._over.get(id(p)) == g["lr"]])
-        return groups
+        return [[p for p in self.reducer.params if self._group_of[id(p)] is g] for g in self.param_groups]
 
     def state_dict(self, layout="flat"):
         """layout="flat" (default): flat moments + step count + per-group learning rates; tensors are clones (safe to
@@ -155,21 +155,17 @@ class FlatAdamW:
             raise ValueError("FlatAdamW.load_state_dict: the torch AdamW checkpoint groups its parameters differently "
                              f"({[len(g['params']) for g in sd['param_groups']]} vs {[len(pl) for pl in order]}): build the "
                              "optimizer with the same lr_overrides (diff_lr) as the run that wrote it")
-        steps = set()
-        self.exp_avg.zero_()
-        self.exp_avg_sq.zero_()
-        for g, sg, plist in zip(self.param_groups, sd["param_groups"], order):
-            g["lr"], g["initial_lr"] = float(sg["lr"]), float(sg.get("initial_lr", sg["lr"]))
+        # validate everything first, write afterwards: a checkpoint that is refused leaves the optimizer as it was
+        steps, writes = set(), []
+        for sg, plist in zip(sd["param_groups"], order):
             for pid, p in zip(sg["params"], plist):
                 st = sd["state"].get(pid)
                 if st is None:
                     continue                          # torch keeps no state for a parameter that never had a gradient
-                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                if tuple(st["exp_avg"].shape) != tuple(p.shape) or tuple(st["exp_avg_sq"].shape) != tuple(p.shape):
                     raise ValueError(f"FlatAdamW.load_state_dict: parameter {pid} has shape {tuple(st['exp_avg'].shape)} in the "
                                      f"checkpoint, {tuple(p.shape)} here")
-                off, n = self._slices[id(p)]
-                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
-                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                writes.append((self._slices[id(p)], st))
                 steps.add(int(float(st["step"])))
         if len(steps) > 1:
             raise ValueError(f"FlatAdamW.load_state_dict: parameters at different step counts {sorted(steps)} (one fused step "
@@ -177,6 +173,13 @@ class FlatAdamW:
         first = sd["param_groups"][0]
         if first.get("amsgrad") or first.get("maximize"):
             raise ValueError("FlatAdamW.load_state_dict: amsgrad / maximize checkpoints are not supported")
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for (off, n), st in writes:
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            g["lr"], g["initial_lr"] = float(sg["lr"]), float(sg.get("initial_lr", sg["lr"]))
         self.betas, self.eps, self.weight_decay = tuple(first["betas"]), float(first["eps"]), float(first["weight_decay"])
         self.steps = steps.pop() if steps else 0
 

@@ -127,7 +127,7 @@ def make_policy(tag):
     return policy, ("in32" not in keep)
 
 
-def run(tag, seed, steps=100, nf=8, B=2, HW=128, threads=2):
+def run(tag, seed, steps=100, decay_from=0, nf=8, B=2, HW=128, threads=2):
     torch.set_num_threads(threads)
     policy, round_inputs = make_policy(tag)
     sd0 = R.make_state_dict(R.jspsr_param_shapes(MSK, nf), 991, torch.float64)
@@ -157,6 +157,9 @@ def run(tag, seed, steps=100, nf=8, B=2, HW=128, threads=2):
 
     for i in range(steps):
         inputs, gt, dem_q = batches[i % 4]
+        if decay_from and i == decay_from:          # the reference's StepLR (common_config.py:339-358), compressed: one drop
+            for grp in opt.param_groups:
+                grp["lr"] *= 0.1
         opt.zero_grad()
         loss = R.multi_loss(fwd(inputs, dem_q, True), gt)["Total"]
         loss.backward()
@@ -167,7 +170,7 @@ def run(tag, seed, steps=100, nf=8, B=2, HW=128, threads=2):
                 pred = fwd(held[0], held[2], False)
             evals.append(MR.mean_scores(pred.numpy(), held[1].numpy(), -80.0, 929.0, 0.05, True))
     win = np.array(losses).reshape(-1, 10).mean(1)
-    return {"tag": tag, "seed": seed, "loss_windows": [float(v) for v in win],
+    return {"tag": tag, "seed": seed, "decay_from": decay_from, "loss_windows": [float(v) for v in win],
             "RMSE": float(np.mean([e["RMSE"] for e in evals])), "PSNR": float(np.mean([e["PSNR"] for e in evals]))}
 
 
@@ -205,8 +208,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--variants", default="fp32,bf16,head,bngrad,gen,dem,allgrad,allfwd,in32,w32")
     ap.add_argument("--out", default="gpurun_out/bf16_policy_ablation.jsonl")
+    ap.add_argument("--decay-from", type=int, default=0, help="multiply the learning rate by 0.1 from this step on (0: never)")
     a = ap.parse_args()
-    jobs = [(v, s, a.steps) for s in range(a.seeds) for v in a.variants.split(",")]
+    jobs = [(v, s, a.steps, a.decay_from) for s in range(a.seeds) for v in a.variants.split(",")]
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     import multiprocessing as mp
     with mp.get_context("spawn").Pool(a.workers) as pool, open(a.out, "a") as f:

@@ -131,6 +131,7 @@ def _hip_trainer(sd64, dtype, lr=1e-3, wd=1e-6, nf=8):
         opt.step()
         return out["Total"].detach()
 
+    step.opt = opt
     return m, step
 
 
@@ -200,56 +201,67 @@ def test_bf16_trains_like_fp32():
     (de-scaled elevations, configs/jspsr_r8_img_msk.yml's range) after steps 70, 80, 90 and 100, averaged (one
     evaluation of a network that is still learning this fast moves by 10 % from one step to the next).
     Two training runs that differ in ANY rounding drift apart (the trajectory test above: 1e-3 after three steps), so
-    "the same curve" has a measured width, and the width is larger in bf16 (tools/lab/bf16_spread.py, five draws each: the
-    held-out RMSE of fp32 runs spreads over 1.69-1.74 m, of bf16 runs over 1.64-2.12 m -- with either propagation kernel,
-    which agree to 2e-5).  FOUR runs therefore: each precision twice, the second from initial parameters perturbed by one
-    fp32 rounding (x (1 + 2^-23 u)).  Stated band, mean of the two bf16 runs vs mean of the two fp32 runs:
-      * mean loss of every 10-step window within 3 x the larger of the two within-precision gaps + 5 %, never beyond 40 %;
-      * the loss falls by more than 90 % over the run in every run (0.048 -> 0.0020-0.0028 when this was written);
-      * held-out RMSE within 3 x the larger within-precision gap + 5 %, never beyond 35 %; PSNR within 3 x + 0.3 dB, never
-        beyond 2.5 dB.
-    What it shows, honestly: in this miniature (8 features, 100 steps) bf16 storage costs 5-25 % of loss at equal step count
-    late in the run and 0-20 % of held-out RMSE -- the same with either propagation kernel, and no more than the oracle
-    with bf16 storage roundings inserted deviates in the forward pass (test above); it is a band, not an identity."""
+    "the same curve" is a distribution, and its tail is heavier in bf16: about one bf16 run in eight ends 15-20 % above
+    the rest (profiles/r04_bf16_policy_ablation.txt: eight draws per precision -- fp32 1.68-1.80 m, bf16 1.56-1.81 m and
+    one run at 2.04).  SIX runs per precision therefore: the unperturbed initial state and five perturbed by one fp32
+    rounding (x (1 + 2^-23 u)); what is compared are the MEANS, against the measured standard error of their difference.
+    Round 4's storage policy is in force (the ablation is in the same profile): everything between
+    layers is bf16 EXCEPT the generator's head -- affinity logits and learned offsets are written, read and
+    differentiated as fp32 planes (csrc/head.hip, jspsr_prop_logits_*).  With the all-bf16 head of round 3 the mean bf16
+    curve ran 11-14 % above fp32 late in the run and the held-out RMSE 2.7 % above; with the fp32 head the windows stay
+    within 8 % and the held-out RMSE comes out 2.6 % BELOW fp32's.  Stated band, mean bf16 vs mean fp32:
+      * mean loss of every 10-step window within 3 standard errors + 5 %, never beyond 15 %;
+      * the loss falls by more than 90 % over the run in every run (0.048 -> 0.0020-0.0028);
+      * held-out RMSE within 3 standard errors + 5 %, never beyond 15 %; PSNR within 3 standard errors + 0.3 dB, never
+        beyond 1 dB."""
     from jspsr_amd import metrics as M
     B, H, W = 2, 128, 128
+    n_draws = 6
     sd64 = R.make_state_dict(R.jspsr_param_shapes(MSK, 8), 991, torch.float64)
-    rs = np.random.RandomState(5)
-    sd_pert = {k: (v * (1 + 2.0 ** -23 * torch.from_numpy(rs.uniform(-1, 1, tuple(v.shape)))) if v.is_floating_point() and v.dim() > 0 and "running" not in k else v.clone())
-               for k, v in sd64.items()}
+
+    def draw(d):
+        if d == 0:
+            return sd64
+        rs = np.random.RandomState(100 + d)
+        return {k: (v * (1 + 2.0 ** -23 * torch.from_numpy(rs.uniform(-1, 1, tuple(v.shape)))) if v.is_floating_point() and v.dim() > 0 and "running" not in k else v.clone())
+                for k, v in sd64.items()}
+
     batches = []
     for s in range(5):
         i64, g64 = R.synthetic_batch(B, H, W, True, seed=1000 + s, dtype=torch.float32)
         batches.append(([t.cuda() for t in i64], g64.cuda()))
     held = batches.pop()
     curves, scores = {}, {}
-    for tag, sd0, dt in (("fp32", sd64, torch.float32), ("fp32'", sd_pert, torch.float32),
-                         ("bf16", sd64, torch.bfloat16), ("bf16'", sd_pert, torch.bfloat16)):
-        m, step = _hip_trainer(sd0, dt)
-        losses, evals = [], []
-        for i in range(100):
-            losses.append(step(*batches[i % 4]).item())
-            if i + 1 in (70, 80, 90, 100):
-                m.eval()
-                with torch.no_grad():
-                    pred = m(*held[0])
-                meter = M.Meter(-80.0, 929.0, border=0.05, elev_log=True)
-                meter.update(pred, held[1])
-                evals.append(meter.scores())
-                m.train()
-        curves[tag] = np.array(losses).reshape(10, 10).mean(1)
-        scores[tag] = {k: float(np.mean([e[k] for e in evals])) for k in ("RMSE", "PSNR")}
-        print(f"{tag:5s} loss per 10-step window " + " ".join(f"{v:.5f}" for v in curves[tag]) + f"; held-out (mean of 4) {scores[tag]}")
-        assert np.isfinite(curves[tag]).all() and curves[tag][-1] < 0.1 * curves[tag][0]
-    w32, w16 = (curves["fp32"] + curves["fp32'"]) / 2, (curves["bf16"] + curves["bf16'"]) / 2
-    spread = max((np.abs(curves["fp32'"] - curves["fp32"]) / w32).max(), (np.abs(curves["bf16'"] - curves["bf16"]) / w16).max())
+    for tag, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        curves[tag], scores[tag] = [], []
+        for d in range(n_draws):
+            m, step = _hip_trainer(draw(d), dt)
+            losses, evals = [], []
+            for i in range(100):
+                losses.append(step(*batches[i % 4]))
+                if i + 1 in (70, 80, 90, 100):
+                    m.eval()
+                    with torch.no_grad():
+                        pred = m(*held[0])
+                    meter = M.Meter(-80.0, 929.0, border=0.05, elev_log=True)
+                    meter.update(pred, held[1])
+                    evals.append(meter.scores())
+                    m.train()
+            w = torch.stack(losses).cpu().numpy().astype(np.float64).reshape(10, 10).mean(1)     # one host sync per run
+            curves[tag].append(w)
+            scores[tag].append({k: float(np.mean([e[k] for e in evals])) for k in ("RMSE", "PSNR")})
+            print(f"{tag} draw {d}: loss per 10-step window " + " ".join(f"{v:.5f}" for v in w) + f"; held-out (mean of 4) {scores[tag][-1]}")
+            assert np.isfinite(w).all() and w[-1] < 0.1 * w[0]
+    c32, c16 = np.array(curves["fp32"]), np.array(curves["bf16"])
+    w32, w16 = c32.mean(0), c16.mean(0)
+    se = np.sqrt(c32.var(0, ddof=1) / n_draws + c16.var(0, ddof=1) / n_draws) / w32
     gap = np.abs(w16 - w32) / w32
-    print(f"window gap, mean bf16 vs mean fp32: " + " ".join(f"{v:.3f}" for v in gap) + f"; largest within-precision gap {spread:.3f}")
-    assert (gap < min(3 * spread + 0.05, 0.40)).all(), (gap, spread)
-    for key, rel_, add, cap in (("RMSE", True, 0.05, 0.35), ("PSNR", False, 0.3, 2.5)):
-        a32, a16 = (scores["fp32"][key] + scores["fp32'"][key]) / 2, (scores["bf16"][key] + scores["bf16'"][key]) / 2
-        norm = a32 if rel_ else 1.0
-        within = max(abs(scores["fp32'"][key] - scores["fp32"][key]), abs(scores["bf16'"][key] - scores["bf16"][key])) / norm
-        d = abs(a16 - a32) / norm
-        print(f"held-out {key}: fp32 {a32:.3f} bf16 {a16:.3f}: gap {d:.3f}, largest within-precision gap {within:.3f}")
-        assert d < min(3 * within + add, cap), (key, d, within)
+    print("window gap, mean bf16 vs mean fp32: " + " ".join(f"{v:.3f}" for v in gap) + "; standard error of the difference " + " ".join(f"{v:.3f}" for v in se))
+    assert (gap < np.minimum(3 * se + 0.05, 0.15)).all(), (gap, se)
+    for key, rel_, add, cap in (("RMSE", True, 0.05, 0.15), ("PSNR", False, 0.3, 1.0)):
+        a32, a16 = (np.array([s_[key] for s_ in scores[t]]) for t in ("fp32", "bf16"))
+        norm = a32.mean() if rel_ else 1.0
+        se_k = np.sqrt(a32.var(ddof=1) / n_draws + a16.var(ddof=1) / n_draws) / norm
+        d = abs(a16.mean() - a32.mean()) / norm
+        print(f"held-out {key}: fp32 {a32.mean():.3f} (sd {a32.std(ddof=1):.3f}) bf16 {a16.mean():.3f} (sd {a16.std(ddof=1):.3f}): gap {d:.3f}, standard error {se_k:.3f}")
+        assert d < min(3 * se_k + add, cap), (key, d, se_k)

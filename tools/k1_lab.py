@@ -49,14 +49,40 @@ def main():
             best = min(best, e0.elapsed_time(e1) / 20 * 1e-3)
         res.append(f"{name} {best * 1e6:6.1f} us {nbytes / best / 1e12:.3f} TB/s ({nbytes / best / 8e12:.3f})")
     print(f"[{tag:28s}] {B}x{H}x{W} s={sigma}: " + " | ".join(res), flush=True)
-    # head-fed entry (K1h): actual bytes moved per pixel = 32 head channels (+ their gradient) + dem + out/gout
+    # the in-model entry (round 4): logits + offsets as planes of one (B,25,H,W) tensor, sigmoid inside the kernel
     from jspsr_amd import _lib, kernels as K
     lib = _lib.load()
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    lsets = [torch.cat((1.5 * torch.randn(B, 9, H, W, device=dev, generator=g), sigma * torch.randn(B, 16, H, W, device=dev, generator=g)), 1)
+             for _ in range(nset)]
+    glsets = [torch.empty_like(t) for t in lsets]
+    lf = lambda i: _lib.check(lib.jspsr_prop_logits_forward_f32(dem.data_ptr(), lsets[i % nset].data_ptr(), w.data_ptr(), b.data_ptr(), 1.0,
+                                                                out.data_ptr(), B, H, W, st()), "lf")
+    lb = lambda i: _lib.check(lib.jspsr_prop_logits_backward_f32(gout.data_ptr(), dem.data_ptr(), lsets[i % nset].data_ptr(), w.data_ptr(),
+                                                                 glsets[i % nset].data_ptr(), None, None, ws.data_ptr(), B, H, W, st()), "lb")
+    res = []
+    for name, fn, nbytes in (("fwd", lf, 108.0 * px), ("bwd", lb, 208.0 * px)):
+        best = 1e9
+        for rep in range(3):
+            for i in range(WARM):
+                fn(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(20):
+                fn(i)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20 * 1e-3)
+        res.append(f"{name} {best * 1e6:6.1f} us {nbytes / best / 1e12:.3f} TB/s ({nbytes / best / 8e12:.3f})")
+    print(f"   in-model logits entry    : " + " | ".join(res), flush=True)
+    del lsets, glsets
+    if os.environ.get("K1_LAB_LEGACY", "1") == "0":
+        return
+    # rounds 2-3's head-fed entry (K1h): actual bytes moved per pixel = 32 head channels (+ their gradient) + dem + out/gout
     for dt, es in ((torch.float32, 4), (torch.bfloat16, 2)):
         heads = [(sigma * torch.randn(B, H, W, 32, device=dev, generator=g)).to(dt) for _ in range(max(2, nset // 2))]
         gheads = [torch.empty_like(h) for h in heads]
         hws = torch.empty(max(lib.jspsr_prop_head_backward_workspace_bytes(B, H, W), 16), dtype=torch.uint8, device=dev)
-        st = lambda: torch.cuda.current_stream().cuda_stream
         hf = lambda i: _lib.check(lib.jspsr_prop_head_forward(K._dt(heads[0]), dem.data_ptr(), heads[i % len(heads)].data_ptr(),
                                                               w.data_ptr(), b.data_ptr(), 1.0, out.data_ptr(), B, H, W, st()), "hf")
         hb = lambda i: _lib.check(lib.jspsr_prop_head_backward(K._dt(heads[0]), gout.data_ptr(), dem.data_ptr(),

@@ -35,17 +35,19 @@ def main():
                      "(tools/profile_round.sh -> tools/k1_pmc_json.py); FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md",
            "shape": "B=8 H=512 W=512, 16-channel offsets / 32-channel head"}
     import re
-    # planar K1: the persistent LDS-DMA kernels, prop_dma_kernel<OC, NW, BWD, NTL, SPLIT>
-    for name, bwd in (("fwd", "false"), ("bwd", "true")):
-        ks = [k for k in F if re.search(r"prop_dma_kernel<\d+, \d+, %s, " % bwd, k)]
-        if not ks or ks[0] not in Wr:
-            continue
-        k = ks[0]
-        out[f"{name}_kernel"] = re.search(r"prop_dma_kernel<[^>]*>", k).group(0)
-        out[f"{name}_fetch_kib_raw"] = round(F[k], 1)
-        out[f"{name}_write_kib"] = round(Wr[k], 1)
-        out[f"{name}_bytes_per_launch"] = int(round((2 * F[k] + Wr[k]) * 1024))
-        out[f"{name}_algorithmic_bytes"] = (108 if name == "fwd" else 208) * px
+    # K1: the persistent LDS-DMA kernels, prop_dma_kernel<OC, NW, BWD, NTL, SPLIT, RP, SIG>: SIG = false at the public
+    # boundary (keys fwd_* / bwd_*), SIG = true for the in-model logits entry (keys logits_fwd_* / logits_bwd_*)
+    for prefix, sig in (("", "false"), ("logits_", "true")):
+        for name, bwd in (("fwd", "false"), ("bwd", "true")):
+            ks = [k for k in F if re.search(r"prop_dma_kernel<\d+, \d+, %s, \w+, \w+, \d+, %s>" % (bwd, sig), k)]
+            if not ks or ks[0] not in Wr:
+                continue
+            k = ks[0]
+            out[f"{prefix}{name}_kernel"] = re.search(r"prop_dma_kernel<[^>]*>", k).group(0)
+            out[f"{prefix}{name}_fetch_kib_raw"] = round(F[k], 1)
+            out[f"{prefix}{name}_write_kib"] = round(Wr[k], 1)
+            out[f"{prefix}{name}_bytes_per_launch"] = int(round((2 * F[k] + Wr[k]) * 1024))
+            out[f"{prefix}{name}_algorithmic_bytes"] = (108 if name == "fwd" else 208) * px
     # K1h: prop_head_dma_kernel<NW, BWD, SPLIT> (bf16 heads: what the models launch), prop_head_kernel<T, BWD> (fp32 heads)
     for dt, es, pat in (("bf16", 2, "__bf16"), ("f32", 4, "float")):
         for name, bwd in (("fwd", "false"), ("bwd", "true")):

@@ -15,6 +15,7 @@ from jspsr_amd import metrics as M  # noqa: E402
 
 draws = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dt = torch.float32 if len(sys.argv) > 2 and sys.argv[2] == "f32" else torch.bfloat16
+decay_from = int(os.environ.get("SPREAD_DECAY_FROM", "0"))     # multiply the learning rate by 0.1 from this step on
 B, H, W = 2, 128, 128
 sd64 = R.make_state_dict(R.jspsr_param_shapes(Fx.MSK, 8), 991, torch.float64)
 batches = []
@@ -29,6 +30,8 @@ for d in range(draws):
     m, step = _hip_trainer(sd, dt)
     losses, evals = [], []
     for i in range(100):
+        if decay_from and i == decay_from:
+            step.opt.lr = step.opt.lr * 0.1
         losses.append(step(*batches[i % 4]).item())
         if i + 1 in (70, 80, 90, 100):
             m.eval()

@@ -11,6 +11,7 @@ mkdir -p ../lib_lab
 for v in "$@"; do
   name=${v%%=*}; flags=""
   case "$v" in *=*) flags=${v#*=};; stamps) flags="-DK1D_STAMPS";; nocompute) flags="-DK1D_NOCOMPUTE";; esac
+  M0_FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags" ./check_m0.sh prop_dma.hip      # the lab -D switches change the code: same M0 guard as the product build
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c prop_dma.hip -o /tmp/k1d_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c prop.hip -o /tmp/k1d_prop_$name.o
   objs=$(ls _obj/*.o | grep -v "_obj/prop.o" | grep -v "_obj/prop_dma.o")

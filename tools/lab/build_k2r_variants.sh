@@ -9,6 +9,7 @@ for la in "$@"; do
   if [ "$la" = "stamps" ]; then extra="-DK2R_STAMPS"; la=4; name=lab_k2r_stamps; fi      # per-phase cycle counters printed by two waves
   case "$la" in e*) extra="-DK2R_EARLY=${la#e}"; name=lab_k2r_$la; la=4;; esac       # e<N>: pieces requested by each of waves 0-3
   case "$la" in o*) o=${la#o}; extra="-DK2R_ORDER=${o%%e*} -DK2R_EARLY=${o##*e}"; name=lab_k2r_$la; la=4;; esac    # o<order>e<N>
+  M0_FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DK2R_LA=$la $extra" ./check_m0.sh conv64.hip      # same M0 guard as the product build
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DK2R_LA=$la $extra -c conv64.hip -o _obj/conv64_la$la.o
   objs=$(ls _obj/*.o | grep -v "conv64")
   [ -z "$name" ] && name=lab_k2r_la$la

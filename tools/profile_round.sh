@@ -25,13 +25,14 @@ cd $root
 python3 tools/kstats.py $out/step 45 > $out/step_kernel_stats.txt
 python3 tools/kstats.py $out/step1s 45 > $out/step1s_kernel_stats.txt
 python3 tools/kstats.py $out/k1 12 > $out/k1_kernel_stats.txt
-python3 tools/kstats.py $out/roof 400 | grep -i "prop_\|^#" > $out/roof_kernel_stats.txt
+python3 tools/kstats.py $out/roof 400 | grep -i "prop_\|head_\|^#" > $out/roof_kernel_stats.txt
 python3 - <<PY >> $out/roof_kernel_stats.txt
 import json
 l = json.loads(open("$out/roof_line.json").readline())["roofline"]
 print("# the same process's JSON line: backward us_per_launch", l["us_per_launch"], l["us_per_launch_reps"], "frac", l["frac"],
       "| forward", l["forward"]["us_per_launch"], l["forward"]["us_per_launch_reps"], "frac", l["forward"]["frac"],
-      "| in-model fwd/bwd us", l["in_model"]["forward"]["us_per_launch"], l["in_model"]["backward"]["us_per_launch"])
+      "| public boundary bwd/fwd us", l["public_boundary"]["us_per_launch"], l["public_boundary"]["forward"]["us_per_launch"],
+      "| K1c heads fwd/bwd us", l["head_conv"]["fwd_us"], l["head_conv"]["bwd_us"])
 PY
 python3 tools/pmc_summary.py $out/k1_fetch prop > $out/k1_pmc_counters.txt
 python3 tools/pmc_summary.py $out/k1_write prop >> $out/k1_pmc_counters.txt
