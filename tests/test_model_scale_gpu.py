@@ -31,6 +31,7 @@ def _count(names):
 
 
 KERNELS = ("conv64_resident", "conv_patch_16x16", "conv_patch", "conv_igemm", "conv2d_wgrad_patch", "conv2d_wgrad",
+           "head_forward", "head_backward", "prop_logits_forward (dma)", "prop_logits_backward (dma)",
            "prop_head_forward", "prop_head_backward", "prop_head_forward (dma)", "prop_head_backward (dma)")
 
 
@@ -74,9 +75,12 @@ def test_benched_architecture_at_a_kernel_selecting_size():
     assert used[torch.bfloat16]["conv_patch_16x16"] >= 1 and used[torch.float32]["conv_patch_16x16"] >= 1, used
     assert used[torch.bfloat16]["conv2d_wgrad_patch"] >= 20 and used[torch.float32]["conv2d_wgrad_patch"] >= 20, used
     assert used[torch.float32]["conv64_resident"] == 0          # K2r is the bf16 kernel
-    # the propagation step: the LDS-DMA kernels for the bf16 head, the 4-lanes-per-pixel kernels for the fp32 one
-    assert used[torch.bfloat16]["prop_head_forward (dma)"] == 1 and used[torch.bfloat16]["prop_head_backward (dma)"] == 1
-    assert used[torch.float32]["prop_head_forward"] == 1 and used[torch.float32]["prop_head_backward"] == 1
+    # the propagation step, either storage type: the heads write fp32 planes (K1c) and the persistent LDS-DMA kernel of the
+    # public boundary reads them (round 4) -- the 32-channel NHWC head kernels of rounds 2-3 are not launched
+    for dt in (torch.float32, torch.bfloat16):
+        assert used[dt]["head_forward"] == 1 and used[dt]["head_backward"] == 1, used
+        assert used[dt]["prop_logits_forward (dma)"] == 1 and used[dt]["prop_logits_backward (dma)"] == 1, used
+        assert not any(used[dt][k] for k in KERNELS if k.startswith("prop_head_")), used
     # fp32
     p32, g32 = out[torch.float32]
     assert (p32 - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
@@ -107,6 +111,54 @@ def test_benched_architecture_at_a_kernel_selecting_size():
     print(f"bf16 prediction relative L2: HIP {d_hip:.2e} (residual only {r_hip:.2e}); emulated oracle {d_emu:.2e} ({r_emu:.2e})")
     assert d_hip < 1.5 * d_emu and r_hip < 1.5 * r_emu
     assert torch.isfinite(pb).all()
+
+
+def test_gradients_against_measured_floors_at_a_k2r_selecting_size():
+    """the kink census and the measured noise floors of the 64 x 64 fixtures
+    (tests/fixtures.py::kink_census / gradient_noise_floor / gradient_tolerances), applied at 2 x 256 x 256 -- 512 tiles of
+    16 x 16, the smallest raster on which the bf16 step selects K2r; in fp32 (the precision a per-tensor comparison means
+    something in) the patch kernels, the nine-tap weight-gradient kernel, K1c and the LDS-DMA propagation kernels run.
+    Every parameter is held to 2 x its OWN measured floor unless the census lists an at-risk kink downstream of it, in
+    which case to 2 x max(own floor, the network's median floor); the tensors furthest above their own floor are printed
+    with the kinks that explain them.  Cost control: one input-rounding draw, the fp32 evaluation and two
+    accumulation-noise draws for the floor; the census walks the at-risk kinks from the output end and stops after
+    `patience` = 2 kinks that add no parameter (the tolerance tiers stay exact, the per-parameter kink lists are subsets)."""
+    from jspsr_amd.JSPSR import Model
+    B, H, W = 2, 256, 256
+    sd64 = R.make_state_dict(R.jspsr_param_shapes(MSK, 32), 5321, torch.float64)
+    in64, _ = R.synthetic_batch(B, H, W, True, seed=5322, dtype=torch.float64)
+    probe = R.probe_gradient((B, 1, H, W), 5323)
+    fwd = lambda sd_, inp: R.jspsr_forward(sd_, inp, True)
+    t0 = time.time()
+    ref, g_ref = Fx.oracle_gradients(fwd, sd64, in64, probe)
+    m = Model(dict(MSK, COP30=1), num_feature=32)
+    m.load_state_dict(Fx.as_f32(sd64))
+    m = m.cuda().train()
+    before = _count(KERNELS)
+    pred = m(*[t.float().cuda() for t in in64])
+    (pred * probe.float().cuda()).mean().backward()
+    torch.cuda.synchronize()
+    used = {k: v - before[k] for k, v in _count(KERNELS).items()}
+    assert used["conv2d_wgrad_patch"] >= 20 and used["conv_patch"] >= 20 and used["prop_logits_backward (dma)"] == 1, used
+    p32 = pred.detach().cpu().double()
+    dev = (p32 - ref).abs().max().item()
+    assert dev < 1e-4 * ref.abs().max().item()
+    grads = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
+    floor = Fx.gradient_noise_floor(fwd, sd64, in64, probe, g_ref, n_trials=1, n_rounding=2, forward_dev=dev, pred_ref=ref)
+    census = Fx.kink_census(fwd, sd64, in64, forward_dev=dev, pred_ref=ref, patience=2)
+    tols, risky = Fx.gradient_tolerances(floor, census)
+    print(f"2x256x256 nf 32 ({time.time() - t0:.0f} s of oracle): " + Fx.describe_census(census).split(chr(10))[0])
+    print(f"  {len(g_ref) - len(risky)} parameters have no at-risk kink downstream (held to 2 x their own floor), {len(risky)} have; "
+          f"median floor {np.median([v[1] for v in floor.values()]):.2e}")
+    rows = sorted(((Fx.rel(grads[k], g_ref[k]), k) for k in g_ref), reverse=True)
+    by_floor = sorted(((e / max(floor[k][1], 1e-30), k, e) for e, k in rows), reverse=True)
+    for ratio, k, e in by_floor[:4]:
+        print(f"  {k}: error {e:.2e} = {ratio:.1f} x own floor {floor[k][1]:.1e}; at-risk kinks downstream: {len(risky.get(k, []))} {risky.get(k, [])[:8]}")
+        assert e <= 2 * floor[k][1] + 1e-5 or k in risky, (k, ratio)
+    worst = sorted(((e / tols[k], k, e, tols[k]) for e, k in rows), reverse=True)
+    print("  worst error / derived tolerance: " + "; ".join(f"{k} {e:.2e}/{t:.2e}" for _, k, e, t in worst[:4])
+          + f"; median error {np.median([e for e, _ in rows]):.2e}")
+    assert worst[0][0] < 1.0, worst[:5]
 
 
 def _hip_trainer(sd64, dtype, lr=1e-3, wd=1e-6, nf=8):

@@ -8,25 +8,51 @@ pytestmark = pytest.mark.gpu
 from oracle import jspsr_ref as R
 
 
-def test_strip_sharding_matches_monolithic():
+def _load(nf, dtype=torch.float32):
     from jspsr_amd.JSPSR import Model
-    from jspsr_amd import tiling
     ic = {"lr_dem": 1, "image": 3, "mask": 15}
-    sd = R.make_state_dict(R.jspsr_param_shapes(ic, 8), seed=3)
-    m = Model(dict(ic, COP30=1), num_feature=8)
+    sd = R.make_state_dict(R.jspsr_param_shapes(ic, nf), seed=3)
+    m = Model(dict(ic, COP30=1), num_feature=nf)
     m.load_state_dict(sd)
     m = m.cuda().eval()
-    inputs, _ = R.synthetic_batch(1, 1024, 256, True, seed=4)
+    m.compute_dtype = dtype
+    return m
+
+
+@pytest.mark.parametrize("nf,H,W,dtype,worlds", [
+    (8, 1024, 256, torch.float32, (2, 4)),
+    # SURVEY 8d / BASELINE config 5's parity check as stated: the benched architecture (image+mask, num_feature 32) on a
+    # 1024 x 1024 scene, 4 and 8 strips (8 = the run's rank count: 128 interior rows + 128-row halos each)
+    (32, 1024, 1024, torch.float32, (4, 8)),
+    (32, 1024, 1024, torch.bfloat16, (4, 8)),
+])
+def test_strip_sharding_matches_monolithic(nf, H, W, dtype, worlds):
+    """fp32: strips == monolithic forward to 2e-5 (what differs is the order of the gate statistics' fp32 sums).
+    bf16 storage: against the monolithic bf16 forward of the same module -- every conv output is bit-identical per pixel
+    (same K order whatever the tile), the gate statistics differ in the last fp32 bits, and a bf16 rounding that lands on
+    the other side (1 ulp = 0.4 %) then travels: stated bound relative L2 < 1e-3 and max |diff| < 2e-2 x max |prediction|.
+    The learned offsets are measured in the run and must fit the halo: max |offset| + 97 <= 128."""
+    from jspsr_amd import tiling
+    m = _load(nf, dtype)
+    inputs, _ = R.synthetic_batch(1, H, W, True, seed=4)
     inputs = [t.cuda() for t in inputs]
     with torch.no_grad():
         mono = m(*inputs)
-    for world in (2, 4):
-        out = tiling.emulate_sharded_forward(m, inputs, world, halo=128)
+    for world in worlds:
+        out, reach = tiling.emulate_sharded_forward(m, inputs, world, halo=128, return_reach=True)
         assert out.shape == mono.shape
+        assert 0 < max(reach) and max(reach) + tiling.RECEPTIVE_RADIUS <= 128, reach
         err = (out - mono).abs().max().item()
-        assert err < 2e-5, (world, err)
+        rel = ((out - mono).norm() / mono.norm()).item()
+        print(f"nf {nf} {H}x{W} {dtype} {world} strips: max |diff| {err:.2e}, relative L2 {rel:.2e}, max |offset| {max(reach):.2f} px")
+        if dtype == torch.float32:
+            assert err < 2e-5, (world, err)
+        else:
+            assert rel < 1e-3 and err < 2e-2 * mono.abs().max().item(), (world, err, rel)
+    if dtype != torch.float32:
+        return
     # without the scene-wide gate statistics the strips disagree: the sync is doing real work
-    strips = tiling.plan_strips(1024, 4, 128)
+    strips = tiling.plan_strips(H, worlds[-1], 128)
     with torch.no_grad():
         naive = torch.cat([m(*[t[:, :, s.ty0:s.ty1].contiguous() for t in inputs])[:, :, s.y0 - s.ty0:s.y1 - s.ty0]
                            for s in strips], 2)
@@ -42,14 +68,10 @@ def test_training_mode_is_rejected():
         tiling.emulate_sharded_forward(m, x, 2)
 
 
-def _model_and_scene(H=1024, W=256):
-    from jspsr_amd.JSPSR import Model
-    ic = {"lr_dem": 1, "image": 3, "mask": 15}
-    sd = R.make_state_dict(R.jspsr_param_shapes(ic, 8), seed=3)
-    m = Model(dict(ic, COP30=1), num_feature=8)
-    m.load_state_dict(sd)
+def _model_and_scene(nf=32, H=1024, W=1024):
+    m = _load(nf)
     inputs, _ = R.synthetic_batch(1, H, W, True, seed=4)
-    return m.cuda().eval(), inputs
+    return m, inputs
 
 
 def _rank_owning_only_its_rows(rank, world, port, outdir):
@@ -79,7 +101,8 @@ def _rank_owning_only_its_rows(rank, world, port, outdir):
 
 def test_two_ranks_each_owning_only_its_strip_match_monolithic(tmp_path):
     """The real cross-process path of config 5: exchange_window (neighbour send/recv) composed with the
-    sharded forward and the cross-rank gate-statistics all-reduce (_combine_ranks), two ranks over gloo."""
+    sharded forward and the cross-rank gate-statistics all-reduce (_combine_ranks), two ranks over gloo -- at the size and
+    architecture SURVEY 8d names (image+mask, num_feature 32, 1024 x 1024, fp32)."""
     import os
     import socket
     import torch.multiprocessing as mp
