@@ -7,7 +7,8 @@ autograd accumulates straight into the communication buffer (no copy in, no copy
 are filled in reverse parameter order -- the order backward produces gradients -- and each
 bucket's all-reduce is issued asynchronously from an autograd hook the moment its last
 gradient lands, overlapping the remaining backward.  BatchNorm statistics stay per replica
-(plain data-parallel semantics, matching the reference's numerics at the per-GPU batch).
+(plain data-parallel semantics, matching the reference's numerics at the per-GPU batch); the running statistics are
+averaged over the replicas on demand (`sync_buffers`, `GradReducer.sync_buffers`: before a checkpoint / evaluation).
 """
 from __future__ import annotations
 
@@ -62,6 +63,11 @@ class GradReducer:
         for p in self.params:
             p._jspsr_direct_grad = True
             p._jspsr_grad_ready = self._direct_ready
+
+    def sync_buffers(self, module: torch.nn.Module):
+        """Average the module's BatchNorm running statistics over this reducer's process group (module-level
+        `sync_buffers`); call before writing a checkpoint or evaluating, so that what rank 0 saves is the job's, not its own."""
+        return sync_buffers(module, self.group)
 
     def attach(self, module: torch.nn.Module):
         """Let `module.zero_grad(...)` -- what the reference's loop calls every iteration with set_to_none=True
@@ -161,6 +167,38 @@ class GradReducer:
         self._works = []
         self.flat.div_(self.world)
         self._reduced = [0] * len(self.buckets)      # a second finish() without a new step is an error too
+
+
+def sync_buffers(module: torch.nn.Module, group=None):
+    """Make every replica's BatchNorm running statistics the MEAN over the replicas ("running stats kept in
+    sync").  Training keeps per-replica batch statistics (plain data-parallel semantics, the reference's numerics at the
+    per-GPU batch), so after the initial broadcast the running_mean / running_var of the replicas drift apart and a
+    checkpoint written by rank 0 would carry rank 0's only.  Call before a checkpoint is written and before evaluation:
+    ONE all-reduce over a flat copy of all floating-point buffers (a few hundred KB), integer buffers
+    (num_batches_tracked: identical on every replica by construction) are checked, not averaged."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    fl = [b for b in module.buffers() if b.is_floating_point()]
+    ints = [b for b in module.buffers() if not b.is_floating_point()]
+    if fl:
+        flat = torch.cat([b.detach().reshape(-1).float() for b in fl])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        off = 0
+        for b in fl:
+            n = b.numel()
+            b.data.copy_(flat[off:off + n].view_as(b))
+            off += n
+    if ints:
+        mine = torch.stack([b.detach().reshape(-1)[0].to(torch.int64) for b in ints])
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("sync_buffers: the replicas disagree on an integer buffer (num_batches_tracked): they did not "
+                               "run the same number of training steps")
+    return len(fl)
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):

@@ -142,3 +142,55 @@ def test_shared_layer_with_direct_gradients_is_refused(monkeypatch):
     p._jspsr_grad_ready(p)
     with pytest.raises(RuntimeError, match="more than once"):
         p._jspsr_grad_ready(p)
+
+
+def _worker_buffers(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jspsr_amd.ddp import GradReducer, broadcast_module, sync_buffers
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 3, padding=1), torch.nn.BatchNorm2d(4), torch.nn.ReLU(), torch.nn.Conv2d(4, 1, 1))
+    broadcast_module(net)
+    red = GradReducer(net.parameters())
+    g = torch.Generator().manual_seed(rank)         # a different shard per rank: the running statistics drift apart
+    net.train()
+    for _ in range(3):
+        red.zero_grad()
+        net(torch.randn(4, 2, 8, 8, generator=g) * (1 + rank)).mean().backward()
+        red.finish()
+    bn = net[1]
+    before = (bn.running_mean.clone(), bn.running_var.clone())
+    n = red.sync_buffers(net)
+    # a replica that ran a different number of steps is refused (num_batches_tracked must agree)
+    if rank == 1:
+        bn.num_batches_tracked += 1
+    try:
+        sync_buffers(net)
+        refused = False
+    except RuntimeError:
+        refused = True
+    q.put((rank, n, [t.numpy().copy() for t in before], [bn.running_mean.numpy().copy(), bn.running_var.numpy().copy()],
+           int(bn.num_batches_tracked), refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_buffers_averages_running_statistics_world2_gloo():
+    """BatchNorm statistics are per replica during training; before a checkpoint the running statistics
+    become the mean over the replicas (GradReducer.sync_buffers) so that rank 0 saves the job's, not its own."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_buffers, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, n0, b0, a0, t0, r0), (_, n1, b1, a1, t1, r1) = res
+    assert n0 == n1 == 2 and t0 == 3 and r0 and r1
+    for i in range(2):
+        assert abs(b0[i] - b1[i]).max() > 1e-3                       # they had drifted
+        assert abs(a0[i] - (b0[i] + b1[i]) / 2).max() < 1e-6         # and are now the mean, on both ranks
+        assert abs(a0[i] - a1[i]).max() == 0

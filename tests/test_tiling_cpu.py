@@ -83,3 +83,43 @@ def test_exchange_window_follows_the_strip_plan_gloo_world3():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == (0, 32) and res[1][2] == (16, 16) and res[2][2] == (32, 0)   # 2*halo towards the only neighbour
+
+
+def _worker_window8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jspsr_amd.tiling import exchange_window, plan_strips
+    H, halo, Wd = 4096, 128, 6                     # BASELINE config 5's scene height and halo over its 8 ranks (narrow: row logic only)
+    strips = plan_strips(H, world, halo)
+    s = strips[rank]
+    rows = torch.arange(s.y0, s.y1, dtype=torch.float32).view(1, 1, -1, 1)
+    mine = torch.cat([rows * 8 + c + torch.arange(Wd, dtype=torch.float32).view(1, 1, 1, Wd) / 16 for c in range(3)], 1)   # value names (row, channel, column)
+    got = exchange_window(mine, strips)
+    wr = torch.arange(s.ty0, s.ty1, dtype=torch.float32).view(1, 1, -1, 1)
+    want = torch.cat([wr * 8 + c + torch.arange(Wd, dtype=torch.float32).view(1, 1, 1, Wd) / 16 for c in range(3)], 1)
+    q.put((rank, bool(torch.equal(got, want)), (s.y0, s.y1, s.ty0, s.ty1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_window_world8_at_4096_rows():
+    """the strip plan and the neighbour exchange at config 5's own geometry -- 4096 rows, 8 ranks,
+    128-row halos: 512 interior rows each, 768-row windows, the two border ranks fetching 256 rows from their one neighbour."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_window8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    for r, _, (y0, y1, ty0, ty1) in res:
+        assert (y0, y1) == (512 * r, 512 * (r + 1)) and ty1 - ty0 == 768
+        assert (ty0, ty1) == ((0, 768) if r == 0 else (4096 - 768, 4096) if r == 7 else (y0 - 128, y1 + 128))
