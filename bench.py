@@ -542,13 +542,16 @@ def main():
     host_ms, abi_calls = (time.perf_counter() - h0) * 1e3, _lib.calls - c0
     torch.cuda.synchronize()
 
-    fp32 = None
-    if world == 1 and args.dtype == "bf16" and not args.no_fp32:
-        fp32 = fp32_legs(args, device, model, step)
+    # the roofline leg runs right behind the training steps -- the state the kernels run in inside the model.  Behind
+    # the fp32 legs (seconds of fp32 MFMA work at the power limit) the same HBM-bound launches read 12-15 % slower on this
+    # pool's boxes (89.5 vs 78.1 us for the backward on one box, profiles/r04_*), which is the chip's power state, not the kernel.
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = time_k1(model, inputs)
         roof["convs"] = time_convs(args.batch, model.compute_dtype)
+    fp32 = None
+    if world == 1 and args.dtype == "bf16" and not args.no_fp32:
+        fp32 = fp32_legs(args, device, model, step)
     infer = None
     if rank == 0 and world == 1 and not args.no_inference:
         infer = inference_leg(model, device)
@@ -575,7 +578,10 @@ def main():
             "config": {
                 "workload": "jspsr_r8_img_msk (image+mask guided, 43.87M params), "
                             f"{args.batch} x {TILE}x{TILE} tiles per GPU, train step "
-                            "(fwd + L1/L2/Sobel loss + bwd + grad all-reduce + AdamW)",
+                            "(fwd + L1/L2/Sobel loss + bwd + grad all-reduce + AdamW)"
+                            + ("; storage policy: bf16 activations / gradients / MFMA operands, fp32 accumulation, BatchNorm statistics, "
+                               "master weights and optimizer, and the generator head (affinity logits + offsets) kept as fp32 planes"
+                               if args.dtype == "bf16" else "; fp32 storage"),
                 "tiles_per_gpu": args.batch, "tile": TILE, "global_tiles": args.batch * world,
                 "parallelism": f"dp{world}", "final_loss": round(final_loss, 6),
             },
