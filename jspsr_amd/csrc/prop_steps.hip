@@ -7,9 +7,14 @@
 //       out = b0 + sum_k wk[k] a_k S_k + scale * dem
 //   * the gradient with respect to the propagated raster itself, because iteration i+1 reads iteration i's output:
 //       grad_dem[q] += sum_{p,k} g_p wk[k] m_k(p) dS_k(p)/d dem[q]  (+ scale * g_q)
-//     a bilinear SCATTER of every tap into its four corners.  Corners inside tile + halo are accumulated in an LDS
-//     tile (ds_add_f32) and flushed once per workgroup with global float atomics; far taps add to global directly.
-//     Float atomics make grad_dem order-dependent in the last bits (everything else stays bit-reproducible).
+//     a bilinear SCATTER of every tap into its four corners.  Round 4: no float atomics on the common path.  Corners inside
+//     tile + halo are accumulated in the tile's LDS window as 64-bit FIXED-POINT integers (ds_add_u64: exact, order-
+//     independent; scale chosen per tile), the window (24 x 80) is written back as floats to a compact buffer in the
+//     workspace, and a second, pixel-ordered pass (prop_step_gdem_gather_kernel) lets every pixel GATHER the 3..6 windows
+//     that cover it, in fixed order, and adds the sum into grad_dem.  Rounds 2-3 used ds_add_f32 (~170 cycles per wave
+//     instruction on gfx950: 320 of the kernel's 450 us) and flushed every window with device-scope float atomics.
+//     Only taps BEYOND tile + halo (|offset| > 8 px) still add to grad_dem with global float atomics, so grad_dem is
+//     bit-reproducible whenever no such tap exists (everything else always is).
 //   * gradients of the fixed affinities / offsets SUMMED over the iterations -> ACC: add into grad_weight / grad_offset.
 // Same tile (8 x 64, one pixel per lane), same LDS staging and border rule as prop.hip.
 #include "prop_tile.h"
@@ -38,9 +43,17 @@ __device__ __forceinline__ constexpr int soch(int k, int c) {
 }
 
 // Bilinear scatter of `v` into the four corners of (py, px): the transpose of corners_fast().
+// Corners inside tile + halo go to the tile's LDS window as 64-BIT FIXED-POINT integers (ds_add_u64): on gfx950 a
+// ds_add_f32 costs ~170 cycles per wave instruction (measured: 36 of them per pixel were 320 of the kernel's 450 us,
+// profiles/r04_k1s_backward.txt) while the integer atomics run at the LDS's normal rate -- and integer addition is
+// associative, so the window's content does not depend on the order the waves arrive in (bit-reproducible without
+// per-wave windows).  `fscale` = 2^e, chosen per tile so that the largest |contribution| sits at 2^45: 24 significant bits
+// of every fp32 product survive exactly, and 2^17 such terms cannot overflow.
+__device__ __forceinline__ unsigned long long to_fixed(float c) { return (unsigned long long)(long long)c; }
+
 template <int LH, int LW>
-__device__ __forceinline__ void scatter_corners(float* __restrict__ ldsacc, float* __restrict__ gimg, int H, int W,
-                                                int ly0, int lx0, float py, float px, float v) {
+__device__ __forceinline__ void scatter_corners(unsigned long long* __restrict__ ldsacc, float* __restrict__ gimg, int H, int W,
+                                                int ly0, int lx0, float py, float px, float v, float fscale) {
   const float fy = floorf(py), fx = floorf(px);
   const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
   const int y0 = (int)fminf(fmaxf(fy, -1.0e9f), 1.0e9f), x0 = (int)fminf(fmaxf(fx, -1.0e9f), 1.0e9f);
@@ -48,12 +61,23 @@ __device__ __forceinline__ void scatter_corners(float* __restrict__ ldsacc, floa
   const bool inl = (unsigned)ry < (unsigned)(LH - 1) && (unsigned)rx < (unsigned)(LW - 1);
   const bool near = (py > -2.f) && (py < (float)(H + 1)) && (px > -2.f) && (px < (float)(W + 1));
   if (inl) {
-    float* p = ldsacc + ry * LW + rx;      // slots outside the raster collect values that are never flushed
-    __hip_atomic_fetch_add(p, v * hy * hx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(p + 1, v * hy * lx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(p + LW, v * ly * hx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(p + LW + 1, v * ly * lx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned long long* p = ldsacc + ry * LW + rx;      // slots outside the raster collect values that are never gathered
+    const float vs = v * fscale;                        // exact: a power of two
+#ifdef K1S_LAB_F32ATOMICS                               // lab: rounds 2-3's ds_add_f32 on the low words (timing only, WRONG results)
+    float* q_ = reinterpret_cast<float*>(p);
+    __hip_atomic_fetch_add(q_, vs * hy * hx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q_ + 2, vs * hy * lx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q_ + 2 * LW, vs * ly * hx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(q_ + 2 * LW + 2, vs * ly * lx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    atomicAdd(p, to_fixed(vs * hy * hx));
+    atomicAdd(p + 1, to_fixed(vs * hy * lx));
+    atomicAdd(p + LW, to_fixed(vs * ly * hx));
+    atomicAdd(p + LW + 1, to_fixed(vs * ly * lx));
+#endif
   } else if (near) {
+    // a tap beyond tile + halo (|offset| > 8 px): global float atomics -- the one place where grad_dem's last bits depend
+    // on the execution order
     const bool y0ok = (unsigned)y0 < (unsigned)H, y1ok = (unsigned)(y0 + 1) < (unsigned)H;
     const bool x0ok = (unsigned)x0 < (unsigned)W, x1ok = (unsigned)(x0 + 1) < (unsigned)W;
     float* q = gimg + (ptrdiff_t)y0 * W + x0;
@@ -128,9 +152,11 @@ __global__ __launch_bounds__(NT) void prop_step_bwd_kernel(const float* __restri
                                                           const float* __restrict__ weight, const float* __restrict__ offset,
                                                           const float* __restrict__ wk, float scale,
                                                           float* __restrict__ gweight, float* __restrict__ goffset,
-                                                          float* __restrict__ gdem, float* __restrict__ partial, SGeom g) {
+                                                          float* __restrict__ gdem, float* __restrict__ partial, float* __restrict__ windows,
+                                                          SGeom g) {
   __shared__ __attribute__((aligned(16))) float lds[SLH * SLW];
-  __shared__ __attribute__((aligned(16))) float ldsacc[GDEM ? SLH * SLW : 4];
+  __shared__ __attribute__((aligned(16))) unsigned long long ldsacc[GDEM ? SLH * SLW : 2];     // the tile's window, 64-bit fixed point
+  __shared__ float tmax[NT / 64];
   __shared__ float red[NT / 64][NRED];
   int b, ty0, tx0;
   stile_coords(g, b, ty0, tx0);
@@ -140,13 +166,53 @@ __global__ __launch_bounds__(NT) void prop_step_bwd_kernel(const float* __restri
   float* gimg = GDEM ? gdem + (size_t)b * P : nullptr;
   stage_dem<SLH, SLW>(lds, img, ty0, tx0, H, W, g.dem_vec4 != 0);
   if (GDEM)
-    for (int i = threadIdx.x; i < SLH * SLW; i += NT) ldsacc[i] = 0.f;
+    for (int i = threadIdx.x; i < SLH * SLW / 2; i += NT) reinterpret_cast<uint4*>(ldsacc)[i] = make_uint4(0u, 0u, 0u, 0u);
   float wreg[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) wreg[k] = wk[k];
-  __syncthreads();
   const int x = tx0 + (int)(threadIdx.x % STW);
   const int ly0 = ty0 - HALO, lx0 = tx0 - HALO;
+  if (GDEM) {
+    // the tile's largest |contribution| to the raster gradient (g w_k m_k before the bilinear weights, and scale * g): sets
+    // the fixed-point scale.  gout and the nine affinities are read here and again in the main loop (from L2 / L1 then).
+    float cmax = 0.f;
+    if (x < W) {
+      for (int y = ty0 + (int)(threadIdx.x / STW); y < min(ty0 + STH, H); y += SRPP) {
+        const size_t pix = (size_t)y * W + x;
+        const float* wp = weight + (size_t)b * 9 * P + pix;
+        const float gj = gout[(size_t)b * P + pix];
+        float a[9], mean = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] = wp[k * P];
+        if (NORM) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) s_ += a[k];
+          mean = s_ / 9.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float c = fabsf(gj * wreg[k] * (a[k] - mean));
+          if (c <= 3.0e38f) cmax = fmaxf(cmax, c);        // (false for NaN / inf: such a tap is dropped below)
+        }
+        const float r_ = fabsf(scale * gj);
+        if (r_ <= 3.0e38f) cmax = fmaxf(cmax, r_);
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, d, 64));
+    if ((threadIdx.x & 63) == 0) tmax[threadIdx.x >> 6] = cmax;
+  }
+  __syncthreads();
+  float fscale = 1.f;
+  int fexp = 0;
+  if (GDEM) {
+    float t_ = tmax[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) t_ = fmaxf(t_, tmax[w]);
+    fexp = t_ > 0.f ? min(100, 45 - ilogbf(t_)) : 0;       // the largest term lands in [2^45, 2^46)
+    fscale = ldexpf(1.f, fexp);
+  }
   float sums[NRED];
 #pragma unroll
   for (int i = 0; i < NRED; ++i) sums[i] = 0.f;
@@ -195,11 +261,11 @@ __global__ __launch_bounds__(NT) void prop_step_bwd_kernel(const float* __restri
         gm[k] = gj * wreg[k] * S;
         gsum += gm[k];
         sums[k] += gj * m * S;
-        if (GDEM) scatter_corners<SLH, SLW>(ldsacc, gimg, H, W, ly0, lx0, py, px, coef);
+        if (GDEM) scatter_corners<SLH, SLW>(ldsacc, gimg, H, W, ly0, lx0, py, px, fabsf(coef) <= 3.0e38f ? coef : 0.f, fscale);
       }
       sums[9] += gj;
-      if (GDEM && scale != 0.f)
-        __hip_atomic_fetch_add(ldsacc + (y - ly0) * SLW + (x - lx0), scale * gj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (GDEM && scale != 0.f && fabsf(scale * gj) <= 3.0e38f)
+        atomicAdd(ldsacc + (y - ly0) * SLW + (x - lx0), to_fixed(scale * gj * fscale));
       if (NORM) {
         gsum /= 9.f;
 #pragma unroll
@@ -236,13 +302,51 @@ __global__ __launch_bounds__(NT) void prop_step_bwd_kernel(const float* __restri
     for (int w = 0; w < NT / 64; ++w) v += red[w][threadIdx.x];
     partial[(size_t)blockIdx.x * NRED + threadIdx.x] = v;
   }
-  if (GDEM) {   // flush the tile's accumulated scatter (barrier above: every ds_add has been issued and has landed)
-    for (int i = threadIdx.x; i < SLH * SLW; i += NT) {
-      const float v = ldsacc[i];
-      const int gy_ = ly0 + i / SLW, gx_ = lx0 + i % SLW;
-      if (v != 0.f && (unsigned)gy_ < (unsigned)H && (unsigned)gx_ < (unsigned)W)
-        __hip_atomic_fetch_add(gimg + (size_t)gy_ * W + gx_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (GDEM) {
+    // the tile's window, back from fixed point (barrier above: every ds_add has landed), written whole -- 24 x 80 floats, plain
+    // 16-byte stores -- to this tile's slot of the window buffer; the gather pass does the rest
+    const int t = jspsr::xcd_contiguous(blockIdx.x, g.nblk);
+    float4* dst = reinterpret_cast<float4*>(windows + (size_t)t * (SLH * SLW));
+    const double inv = ldexp(1.0, -fexp);
+    for (int i = threadIdx.x; i < SLH * SLW / 4; i += NT) {
+      const long long* a_ = reinterpret_cast<const long long*>(ldsacc) + 4 * i;
+      dst[i] = make_float4((float)((double)a_[0] * inv), (float)((double)a_[1] * inv), (float)((double)a_[2] * inv), (float)((double)a_[3] * inv));
     }
+  }
+}
+
+// Second pass of the raster gradient: pixel (b, y, x) of tile (ty, tx) is covered by the windows of tiles (ty + dy, tx + dx),
+// dy in {-1, 0, 1} (a window is 24 rows tall: 8 of halo either side of its 8 rows) and dx = -1 / +1 only within 8 pixels of
+// the tile's left / right edge.  Four pixels per lane, fixed order of the (up to 6) terms, sum ADDED into grad_dem.
+__global__ __launch_bounds__(256) void prop_step_gdem_gather_kernel(const float* __restrict__ windows, float* __restrict__ gdem, SGeom g) {
+  const int W4 = (g.W + 3) / 4;
+  const long long n = (long long)g.B * g.H * W4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W4) * 4;
+    const long long r = i / W4;
+    const int y = (int)(r % g.H), b = (int)(r / g.H);
+    const int ty = y / STH, tx = x / STW, xr = x - tx * STW;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int tyy = ty + dy;
+      if (tyy < 0 || tyy >= g.tiles_y) continue;
+      const int wy = y - (tyy * STH - HALO);                  // row of this pixel inside that tile's window: 0 .. 23 by construction
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int txx = tx + dx;
+        if (txx < 0 || txx >= g.tiles_x) continue;
+        if ((dx < 0 && xr >= HALO) || (dx > 0 && xr + 4 <= STW - HALO)) continue;      // (x % 4 == 0 and HALO % 4 == 0: all four pixels or none)
+        const int wx = x - (txx * STW - HALO);
+        const float* wrow = windows + ((size_t)((size_t)b * g.tiles_y + tyy) * g.tiles_x + txx) * (SLH * SLW) + wy * SLW + wx;
+        const float4 v = *reinterpret_cast<const float4*>(wrow);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      }
+    }
+    float* q = gdem + ((size_t)b * g.H + y) * g.W + x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x + j < g.W) q[j] += acc[j];
   }
 }
 
@@ -284,7 +388,8 @@ extern "C" int jspsr_prop_step_forward_f32(const float* dem, const float* weight
 extern "C" size_t jspsr_prop_step_backward_workspace_bytes(int B, int H, int W) {
   SGeom g;
   if (make_sgeom(B, H, W, g)) return 0;
-  return ((size_t)g.nblk * NRED * sizeof(float) + 15) & ~(size_t)15;
+  // partial rows of the parameter gradients, then one 24 x 80 window per tile for the raster gradient's gather pass
+  return (((size_t)g.nblk * NRED * sizeof(float) + 15) & ~(size_t)15) + (size_t)g.nblk * SLH * SLW * sizeof(float);
 }
 
 extern "C" int jspsr_prop_step_backward_f32(const float* grad_out, const float* dem, const float* weight, const float* offset,
@@ -306,7 +411,8 @@ extern "C" int jspsr_prop_step_backward_f32(const float* grad_out, const float* 
   g.dem_vec4 = (W % 4 == 0) && jspsr::aligned16(dem);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
-#define GO(OC, NORM, GD, AC) hipLaunchKernelGGL((prop_step_bwd_kernel<OC, NORM, GD, AC>), dim3(g.nblk), dim3(NT), 0, s, grad_out, dem, weight, offset, wk, scale, grad_weight, grad_offset, grad_dem, partial, g)
+  float* windows = reinterpret_cast<float*>(static_cast<char*>(workspace) + (((size_t)g.nblk * NRED * sizeof(float) + 15) & ~(size_t)15));
+#define GO(OC, NORM, GD, AC) hipLaunchKernelGGL((prop_step_bwd_kernel<OC, NORM, GD, AC>), dim3(g.nblk), dim3(NT), 0, s, grad_out, dem, weight, offset, wk, scale, grad_weight, grad_offset, grad_dem, partial, windows, g)
 #define BY_AC(OC, NORM, GD) do { if (accumulate) GO(OC, NORM, GD, true); else GO(OC, NORM, GD, false); } while (0)
 #define BY_GD(OC, NORM) do { if (grad_dem) BY_AC(OC, NORM, true); else BY_AC(OC, NORM, false); } while (0)
 #define BY_NORM(OC) do { if (normalize) BY_GD(OC, true); else BY_GD(OC, false); } while (0)
@@ -316,6 +422,12 @@ extern "C" int jspsr_prop_step_backward_f32(const float* grad_out, const float* 
 #undef BY_AC
 #undef GO
   if (int e = jspsr::check_launch("prop_step_backward")) return e;
+  if (grad_dem) {
+    const long long n4 = (long long)B * H * ((W + 3) / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(prop_step_gdem_gather_kernel, dim3(blocks), dim3(256), 0, s, windows, grad_dem, g);
+    if (int e = jspsr::check_launch("prop_step_gdem_gather")) return e;
+  }
   if (!grad_wk) return JSPSR_OK;
   hipLaunchKernelGGL(prop_bwd_finalize, dim3(NRED), dim3(256), 0, s, partial, g.nblk, grad_wk, grad_b0);
   return jspsr::check_launch("prop_step_backward_finalize");
