@@ -558,33 +558,44 @@ bool wgrad_patch_enabled() {
 }
 
 // dW[r][c][ky][kx] (+)= sum_z ws[z][r][(ky*KW+kx)*Cx + c],  r < R, c < C  (fixed summation order).
-// A (32 x 8)-thread workgroup owns 32 consecutive slab elements (128-byte coalesced reads of every
-// slab); its 8 z-lanes each sum every 8th slab, then fold in a fixed order.  The scattered 4-byte
-// writes into the (R, C, KH, KW) master layout are the small side.
+// A (32 x 8)-thread workgroup owns 128 consecutive slab elements -- FOUR per lane, one 16-byte load per slab (round 4: the
+// 4-byte loads of rounds 1-3 ran at 1.9 TB/s over ~3 GB of slabs per step); its 8 z-lanes each sum every 8th slab, then
+// fold in a fixed order (the same order per element as before: same bits).  The scattered 4-byte writes into the
+// (R, C, KH, KW) master layout are the small side.  Ktot is a multiple of 4 (Cx is a whole number of 16-byte chunks).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int R,
                                                           int C, int KH, int KW, int Cg, int Cx, int splits,
                                                           int accumulate) {
-  __shared__ float red[8][32];
+  __shared__ float4 red[8][32];
   const int Ktot = KH * KW * Cx;
   const long long total = (long long)R * Ktot;
   const size_t slab = (size_t)Cg * Ktot;
   const int ex = threadIdx.x & 31, zl = threadIdx.x >> 5;
-  for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
-    const long long idx = base + ex;
-    float s = 0.f;
+  for (long long base = (long long)blockIdx.x * 128; base < total; base += (long long)gridDim.x * 128) {
+    const long long idx = base + 4 * ex;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < total)
-      for (int z = zl; z < splits; z += 8) s += ws[z * slab + idx];   // slab rows of G channels < R are a prefix
+      for (int z = zl; z < splits; z += 8) {   // slab rows of G channels < R are a prefix
+        const float4 v = *reinterpret_cast<const float4*>(ws + z * slab + idx);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
     red[zl][ex] = s;
     __syncthreads();
     if (zl == 0 && idx < total) {
-      float t = 0.f;
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) t += red[q][ex];
-      const int r = (int)(idx / Ktot), k = (int)(idx % Ktot);
-      const int tap = k / Cx, c = k % Cx;
-      if (c < C) {
-        const size_t dst = ((size_t)r * C + c) * (KH * KW) + tap;
-        dW[dst] = accumulate ? dW[dst] + t : t;
+      for (int q = 0; q < 8; ++q) {
+        const float4 v = red[q][ex];
+        t[0] += v.x; t[1] += v.y; t[2] += v.z; t[3] += v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long i = idx + j;
+        const int r = (int)(i / Ktot), k = (int)(i % Ktot);
+        const int tap = k / Cx, c = k % Cx;
+        if (c < C) {
+          const size_t dst = ((size_t)r * C + c) * (KH * KW) + tap;
+          dW[dst] = accumulate ? dW[dst] + t[j] : t[j];
+        }
       }
     }
     __syncthreads();
@@ -652,7 +663,7 @@ int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradG
                            static_cast<const T*>(X), ws, q);
       if (int e = check_launch("conv2d_wgrad_patch")) return e;
       const long long total = (long long)R * g.Ktot;
-      const int blocks = (int)((total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096);
+      const int blocks = (int)((total + 127) / 128 < 4096 ? (total + 127) / 128 : 4096);
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dW, R, C, g.KH, g.KW, g.Cg, g.Cx,
                          pp.units, accumulate);
       return check_launch("conv2d_wgrad_reduce");
@@ -673,7 +684,7 @@ int run(const void* G, const void* X, float* dW, int R, int C, float* ws, WgradG
   else e = launch_w<T, 32, 1, 4>(G, X, ws, g, p.splits, s);
   if (e) return e;
   const long long total = (long long)R * g.Ktot;
-  const int blocks = (int)((total + 31) / 32 < 4096 ? (total + 31) / 32 : 4096);
+  const int blocks = (int)((total + 127) / 128 < 4096 ? (total + 127) / 128 : 4096);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dW, R, C, g.KH, g.KW, g.Cg, g.Cx,
                      p.splits, accumulate);
   return check_launch("conv2d_wgrad_reduce");
