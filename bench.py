@@ -453,6 +453,86 @@ def inference_leg(model, device):
                       "rel_l2": float(f"{c_rel:.3e}"), "bound": "fp32 2e-5 abs; bf16 rel L2 1e-3"}}
 
 
+def graph_leg_child(args):
+    """Body of the hipGraph leg (runs in a CHILD process of the bench: `python bench.py --graph-child`): eager vs replayed
+    training step at 2 tiles and at the headline's tile count; prints one JSON object."""
+    from jspsr_amd import _lib
+    from jspsr_amd.JSPSR import Model
+    from jspsr_amd.ddp import GradReducer
+    from jspsr_amd.graph import GraphedStep
+    from jspsr_amd.losses import MultiLoss
+    from jspsr_amd.optim import FlatAdamW
+    _lib.load()
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = Model(in_channels=IN_CHANNELS, out_channels=1, num_feature=32, layers=(2, 2, 2, 2), spn=True).to(device).train()
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    reducer = GradReducer(model.parameters())
+    reducer.watch_streams(model.side_streams(device))
+    opt = FlatAdamW(reducer, lr=1e-3, weight_decay=1e-6)
+    criterion = MultiLoss(1.0, 1.0, 0.1)
+    out = {}
+    for tiles in sorted({2, args.batch}):
+        inputs, gt = synthetic_batch(tiles, TILE, TILE, device, seed=3000 + tiles)
+
+        def eager():
+            reducer.zero_grad()
+            criterion(model(*inputs), gt)["Total"].backward()
+            reducer.finish()
+            opt.step()
+
+        def timed(fn, n):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            host = (time.perf_counter() - t0) / n
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / n * 1e3, 3), round(host * 1e3, 3)
+
+        n = max(5, min(args.steps, 10))
+        e_ms, e_host = timed(eager, n)
+        t0 = time.perf_counter()
+        step = GraphedStep(model, reducer, opt, criterion, inputs, gt)
+        t_cap = time.perf_counter() - t0
+        g_ms, g_host = timed(step, n)
+        out[f"tiles_{tiles}"] = {"eager_ms_per_step": e_ms, "eager_host_ms_per_step": e_host, "graph_ms_per_step": g_ms,
+                                 "graph_host_ms_per_step": g_host, "graph_Mpixel_per_s": round(tiles * TILE * TILE / g_ms / 1e3, 3),
+                                 "capture_s": round(t_cap, 2)}
+        del step, inputs, gt
+        criterion.reset()
+        torch.cuda.empty_cache()
+    print(json.dumps(out), flush=True)
+
+
+def graph_leg(args):
+    """VERDICT r3 item 9: the same training step captured in a hipGraph and replayed (jspsr_amd/graph.py::GraphedStep;
+    bit-identical to the eager step: tests/test_train_step_gpu.py), at 2 tiles per GPU -- where the eager step is bound by
+    the host's ~40 ms of Python / autograd / ctypes per step -- and at the headline's tile count.  Per arm: ms per step and
+    the host time per step (no synchronisation inside the loop).  The headline `value` stays the EAGER step, the reference's
+    loop body as its train loop would run it.  Runs in a child process: a capture the runtime refuses (a stale autograd
+    graph on the default stream ends in a segmentation fault inside hipStreamEndCapture) must not take the line with it."""
+    import subprocess
+    out = {"note": "eager vs hipGraph replay of the full train step (fwd + loss + bwd + AdamW) in a child process, same architecture "
+                   "and storage type; N = 1 only (a captured step holds no collective); the headline value is the eager step"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--batch", str(args.batch), "--steps", str(args.steps),
+           "--dtype", args.dtype]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            out["error"] = f"child exited with {r.returncode}: {(r.stderr or '').strip()[-300:]}"
+        else:
+            out.update(json.loads(lines[-1]))
+    except subprocess.TimeoutExpired:
+        out["error"] = "child timed out"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,7 +546,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 legs (N = 1 only)")
     ap.add_argument("--no-inference", action="store_true", help="skip the whole-scene strip forward (N = 1 only)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-replay leg (N = 1 only)")
+    ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.graph_child:
+        return graph_leg_child(args)
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: start one child process per GPU (nothing in THIS process has touched the GPU
@@ -555,6 +639,10 @@ def main():
     infer = None
     if rank == 0 and world == 1 and not args.no_inference:
         infer = inference_leg(model, device)
+    graph = None
+    if rank == 0 and world == 1 and not args.no_graph:
+        torch.cuda.empty_cache()
+        graph = graph_leg(args)
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:      # on rank 0 at every N: north_star wants the CPU figure "in the same run"
         cpu = cpu_baseline()
@@ -592,6 +680,7 @@ def main():
             "cpu_baseline": cpu,
             "fp32": fp32,
             "inference": infer,
+            "graph": graph,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -346,6 +346,11 @@ int jspsr_metrics_forward(const float* pred, const float* gt, int H, int W, floa
  * 4-byte aligned and share one offset from a 16-byte boundary (sub-ranges of four identically laid out buffers). */
 int jspsr_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, jspsr_stream_t stream);
+/* The same step with its scalars in DEVICE memory, for launches captured in a hipGraph (jspsr_amd/graph.py): hyper[7] =
+ * { lr, beta1, beta2, eps, weight_decay, 1 - beta1^step, sqrt(1 - beta2^step) } (the bias corrections computed by the caller
+ * in double, as torch.optim.AdamW does), refreshed by the caller before every replay. */
+int jspsr_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                         const float* hyper, jspsr_stream_t stream);
 
 /* The MLP between gate_pool and gate_scale (resnet_cbam.py:41-53: two bias-free 1x1 convs C -> Ch -> C shared by the
  * average- and the max-pooled vector, ReLU between, Sigmoid of the sum): s[b,c] = sigmoid(W2 relu(W1 avg[b]) + W2 relu(W1

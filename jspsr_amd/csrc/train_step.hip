@@ -161,6 +161,43 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// The same update with its seven scalars -- lr, beta1, beta2, eps, weight decay, the two bias corrections -- read from DEVICE
+// memory: a launch captured in a hipGraph carries its kernel arguments verbatim, and the learning rate and the bias
+// corrections change from step to step (jspsr_adamw_step_dev; the caller refreshes the seven floats before every replay).
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, long long n, int head,
+                                                       const float* __restrict__ hyper) {
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2s = hyper[6];
+  const long long n4 = (n - head) / 4;
+  float4* p4 = reinterpret_cast<float4*>(p + head);
+  const float4* g4 = reinterpret_cast<const float4*>(g + head);
+  float4* m4 = reinterpret_cast<float4*>(m + head);
+  float4* v4 = reinterpret_cast<float4*>(v + head);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 P = p4[i];
+    const float4 G = g4[i];
+    float4 M = m4[i], V = v4[i];
+    adamw_one(P.x, G.x, M.x, V.x, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    adamw_one(P.y, G.y, M.y, V.y, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    adamw_one(P.z, G.z, M.z, V.z, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    adamw_one(P.w, G.w, M.w, V.w, lr, beta1, beta2, eps, wd, bc1, bc2s);
+    p4[i] = P;
+    m4[i] = M;
+    v4[i] = V;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 8) {  // up to 3 head + 3 tail elements
+    const int tail = (int)(n - head - n4 * 4);
+    long long i = -1;
+    if ((int)threadIdx.x < head) i = threadIdx.x;
+    else if ((int)threadIdx.x >= 4 && (int)threadIdx.x - 4 < tail) i = head + n4 * 4 + (threadIdx.x - 4);
+    if (i >= 0) {
+      float P = p[i], M = m[i], V = v[i];
+      adamw_one(P, g[i], M, V, lr, beta1, beta2, eps, wd, bc1, bc2s);
+      p[i] = P; m[i] = M; v[i] = V;
+    }
+  }
+}
+
 int loss_blocks(long long n) {
   long long b = (n + LT - 1) / LT;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -217,5 +254,21 @@ extern "C" int jspsr_adamw_step(float* param, const float* grad, float* exp_avg,
   const int blocks = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg,
                      exp_avg_sq, n, head, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+  return check_launch("adamw_step");
+}
+
+extern "C" int jspsr_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                                    const float* hyper, jspsr_stream_t stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return fail(JSPSR_EINVAL, "adamw_step_dev: bad arguments");
+  const uintptr_t mis = reinterpret_cast<uintptr_t>(param) & 15;
+  if ((mis & 3) || (reinterpret_cast<uintptr_t>(grad) & 15) != mis || (reinterpret_cast<uintptr_t>(exp_avg) & 15) != mis ||
+      (reinterpret_cast<uintptr_t>(exp_avg_sq) & 15) != mis || (reinterpret_cast<uintptr_t>(hyper) & 3))
+    return fail(JSPSR_EALIGN, "adamw_step_dev: buffers must be 4-byte aligned and equally offset from a 16-byte boundary");
+  int head = (int)(((16 - mis) & 15) >> 2);
+  if (head > n) head = (int)n;
+  long long b = (n / 4 + 255) / 256;
+  const int blocks = (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg,
+                     exp_avg_sq, n, head, hyper);
   return check_launch("adamw_step");
 }

@@ -588,10 +588,11 @@ def _wgrad_async(param, G, X, R, C, KH, KW, stride, pad, **kw):
     # reusable within it (measured: 160 GiB reserved for a 24 GiB working set).  The host therefore never gets more
     # than RUN_AHEAD weight-gradient launches (about five residual blocks) ahead of the GPU -- still far more queued
     # work than the launch latency needs.
-    marks = _marks.setdefault(cur.cuda_stream, collections.deque())
-    marks.append(cur.record_event())
-    if len(marks) > RUN_AHEAD:
-        marks.popleft().synchronize()
+    if not torch.cuda.is_current_stream_capturing():     # (a captured step has a fixed memory plan and no host to throttle)
+        marks = _marks.setdefault(cur.cuda_stream, collections.deque())
+        marks.append(cur.record_event())
+        if len(marks) > RUN_AHEAD:
+            marks.popleft().synchronize()
     if dW is not None:                       # handed to autograd, which consumes it on the home stream
         cur.wait_stream(aux)
         dW.record_stream(cur)

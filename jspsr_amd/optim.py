@@ -67,6 +67,29 @@ class FlatAdamW:
     def lr(self, v):
         self.param_groups[0]["lr"] = float(v)
 
+    # -- scalars in device memory (graph capture: jspsr_amd/graph.py) ----------------------------------------------------
+    def enable_device_hyper(self):
+        """From now on the kernels read lr / betas / eps / weight decay / bias corrections from a small device tensor per
+        parameter group (jspsr_adamw_step_dev) that `upload_hyper()` refreshes -- the launches can then be captured in a
+        hipGraph and replayed while the learning rate and the step count move on.  Same arithmetic, same bits."""
+        if getattr(self, "_hyper_dev", None) is None:
+            n = len(self.param_groups)
+            self._hyper_host = torch.zeros((n, 8), dtype=torch.float32).pin_memory()
+            self._hyper_dev = torch.zeros((n, 8), dtype=torch.float32, device=self.flat_p.device)
+        return self
+
+    def upload_hyper(self, step=None):
+        """Write the seven scalars of every group for step count `step` (default: the current one) into the device tensor;
+        an ordinary stream-ordered copy from pinned memory -- call it OUTSIDE a captured region."""
+        import numpy as np
+        step = self.steps if step is None else step
+        b1, b2 = float(np.float32(self.betas[0])), float(np.float32(self.betas[1]))      # the C side raises the float values
+        bc1, bc2s = 1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5
+        for i, g in enumerate(self.param_groups):
+            self._hyper_host[i, :7] = torch.tensor([g["lr"], self.betas[0], self.betas[1], self.eps, self.weight_decay, bc1, bc2s],
+                                                   dtype=torch.float64).float()
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
     def step(self):
         if not self.flat_p.is_cuda:
             raise RuntimeError("FlatAdamW runs on the GPU only")
@@ -74,12 +97,20 @@ class FlatAdamW:
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
         es = self.flat_p.element_size()
-        for g in self.param_groups:
+        dev = getattr(self, "_hyper_dev", None)
+        if dev is not None and not torch.cuda.is_current_stream_capturing():
+            self.upload_hyper()                 # (under capture the owner of the graph uploads before every replay)
+        for i, g in enumerate(self.param_groups):
             for lo, hi in g["ranges"]:
-                _lib.check(lib.jspsr_adamw_step(self.flat_p.data_ptr() + lo * es, self.reducer.flat.data_ptr() + lo * es,
-                                                self.exp_avg.data_ptr() + lo * es, self.exp_avg_sq.data_ptr() + lo * es,
-                                                hi - lo, g["lr"], self.betas[0], self.betas[1], self.eps,
-                                                self.weight_decay, self.steps, stream), "jspsr_adamw_step")
+                if dev is not None:
+                    _lib.check(lib.jspsr_adamw_step_dev(self.flat_p.data_ptr() + lo * es, self.reducer.flat.data_ptr() + lo * es,
+                                                        self.exp_avg.data_ptr() + lo * es, self.exp_avg_sq.data_ptr() + lo * es,
+                                                        hi - lo, dev[i].data_ptr(), stream), "jspsr_adamw_step_dev")
+                else:
+                    _lib.check(lib.jspsr_adamw_step(self.flat_p.data_ptr() + lo * es, self.reducer.flat.data_ptr() + lo * es,
+                                                    self.exp_avg.data_ptr() + lo * es, self.exp_avg_sq.data_ptr() + lo * es,
+                                                    hi - lo, g["lr"], self.betas[0], self.betas[1], self.eps,
+                                                    self.weight_decay, self.steps, stream), "jspsr_adamw_step")
         ops.invalidate_packed_weights()      # the kernel wrote the parameters through raw pointers ...
         if ops.repack_after_step:
             ops.repack_all()                 # ... and every cached packed copy is re-made here, in one launch

@@ -206,3 +206,68 @@ def test_flat_adamw_exchanges_checkpoints_with_torch_adamw():
         oa.load_state_dict({"state": {}, "param_groups": [{"lr": 1e-3}]})
     with pytest.raises(ValueError, match="groups its parameters differently"):
         oa.load_state_dict(torch.optim.AdamW(mk().parameters()).state_dict())
+
+
+def test_graphed_step_is_bit_identical_to_the_eager_step():
+    """jspsr_amd.graph.GraphedStep: the training step captured in a hipGraph (forward on three streams, fused loss, backward
+    with the weight gradients on their auxiliary streams, FlatAdamW with its scalars in device memory) replays to the
+    SAME BITS as the eager step -- parameters, optimizer moments, BatchNorm buffers and the loss, after 3 eager + 4 replayed
+    steps against 7 eager ones, with a learning-rate change in between (the schedule reaches the replayed launches through
+    the device-side scalars) and a new batch copied into the static inputs."""
+    from jspsr_amd.JSPSR import Model
+    from jspsr_amd.ddp import GradReducer
+    from jspsr_amd.graph import GraphedStep
+    from jspsr_amd.losses import MultiLoss
+    from jspsr_amd.optim import FlatAdamW
+    from oracle import jspsr_ref as R
+    ic = {"lr_dem": 1, "image": 3, "mask": 15}
+    sd = R.make_state_dict(R.jspsr_param_shapes(ic, 8), seed=21)
+    batches = []
+    for s in range(2):
+        inp, gt = R.synthetic_batch(2, 64, 64, True, seed=22 + s)
+        batches.append(([t.cuda() for t in inp], gt.cuda()))
+
+    def build(dtype):
+        m = Model(dict(ic, COP30=1), num_feature=8)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.compute_dtype = dtype
+        red = GradReducer(m.parameters())
+        red.watch_streams(m.side_streams("cuda"))
+        opt = FlatAdamW(red, lr=1e-3, weight_decay=1e-6)
+        return m, red, opt, MultiLoss(1.0, 1.0, 0.1)
+
+    for dtype in (torch.float32, torch.bfloat16):
+        # eager: 7 steps, batch 0 for steps 1-5, batch 1 from step 6; lr halves from step 5 on
+        m, red, opt, crit = build(dtype)
+        losses_e = []
+        for i in range(7):
+            if i == 4:
+                opt.lr = 5e-4
+            inp, gt = batches[0 if i < 5 else 1]
+            red.zero_grad()
+            loss = crit(m(*inp), gt)["Total"]
+            loss.backward()
+            red.finish()
+            opt.step()
+            losses_e.append(loss.item())
+        ref = {k: v.clone() for k, v in m.state_dict().items()}
+        ref_m, ref_v = opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+        # graphed: 3 eager warm-up steps inside the constructor, then 4 replays
+        m, red, opt, crit = build(dtype)
+        step = GraphedStep(m, red, opt, crit, *batches[0], warmup=3)
+        losses_g = []
+        for i in range(3, 7):
+            if i == 4:
+                opt.lr = 5e-4
+            loss = step(*batches[1]) if i == 5 else step()
+            losses_g.append(loss.item())
+        assert opt.steps == 7 and step.replays == 4
+        assert losses_g == losses_e[3:], (dtype, losses_g, losses_e)
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, ref[k]), (dtype, k)
+        assert torch.equal(opt.exp_avg, ref_m) and torch.equal(opt.exp_avg_sq, ref_v)
+        # and the module keeps working eagerly afterwards (packed-weight caches were invalidated)
+        m.eval()
+        with torch.no_grad():
+            assert torch.isfinite(m(*batches[0][0])).all()

@@ -9,12 +9,12 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 python3 $root/bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
 echo "[profile] bench line done"
-rocprofv3 --kernel-trace --stats -f csv -d $out/step -o step -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline --no-inference > $out/step.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $out/step -o step -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline --no-inference --no-graph > $out/step.log 2>&1
 echo "[profile] multi-stream step traced"
-JSPSR_BRANCH_STREAMS=0 JSPSR_WGRAD_ASYNC=0 rocprofv3 --kernel-trace --stats -f csv -d $out/step1s -o step1s -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline --no-inference > $out/step1s.log 2>&1
+JSPSR_BRANCH_STREAMS=0 JSPSR_WGRAD_ASYNC=0 rocprofv3 --kernel-trace --stats -f csv -d $out/step1s -o step1s -- python3 $root/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32 --no-roofline --no-inference --no-graph > $out/step1s.log 2>&1
 echo "[profile] single-stream step traced"
 # the bench line's roofline leg under the profiler: the JSON line and the kernel averages come from ONE process
-rocprofv3 --kernel-trace --stats -f csv -d $out/roof -o roof -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-inference > $out/roof_line.json 2> $out/roof.err
+rocprofv3 --kernel-trace --stats -f csv -d $out/roof -o roof -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-inference --no-graph > $out/roof_line.json 2> $out/roof.err
 echo "[profile] roofline leg traced"
 rocprofv3 --kernel-trace --stats -f csv -d $out/k1 -o k1 -- python3 $root/tools/k1_lab.py > $out/k1.log 2>&1
 echo "[profile] K1 micro-benchmark traced"
