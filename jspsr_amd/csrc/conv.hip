@@ -1030,7 +1030,10 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
       // on MI355X: +5 % on the 64x64x512-channel layers, -3..5 % on the full-resolution ones (one 8-wave workgroup
       // per CU stalls as a whole at each stage barrier; two 4-wave workgroups cover each other) -> opt-in only
       // (JSPSR_CONV_TALL=2).
-      if (tall >= 2 && tiles16 * ((g.Cout + 127) / 128) >= 512) return launch_patch<T, 256, 128, 4, 2>(in, wgt, bias, out, stats, g, s);
+      if (tall == 2 && tiles16 * ((g.Cout + 127) / 128) >= 512) return launch_patch<T, 256, 128, 4, 2>(in, wgt, bias, out, stats, g, s);
+      // lab (JSPSR_CONV_TALL=3): the 64-channel configuration's 16x16-pixel x 64-channel tile for wider layers too -- the patch
+      // is staged once per 64 output channels instead of once per 128, the weight tile once per 256 pixels instead of 128
+      if (tall == 3 && tiles16 * ((g.Cout + 63) / 64) >= 1024) return launch_patch<T, 256, 64, 4, 1>(in, wgt, bias, out, stats, g, s);
       return launch_patch<T, 128, 128, 2, 2>(in, wgt, bias, out, stats, g, s);
     }
     if (g.Cout > 32) {
