@@ -44,6 +44,7 @@ struct DmaArgs {
   // elements between consecutive images of weight / offset (and of their gradients): 9 P / OC P for the two tensors of the
   // public boundary, 25 P for both when they are planes 0..8 / 9..24 of ONE (B,25,H,W) head tensor (SIG form)
   size_t wbs, obs;
+  size_t ps;      // elements between consecutive planes of weight / offset and of their gradients: H W, or a padded pitch
 };
 
 // One tile t of a workgroup's run, operand / DEM buffers t % 2.  Two roles:
@@ -106,7 +107,7 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
   for (int i = 0; i < NPIECE; ++i) {
     const int p = 4 * i + lq;
     const int ch = p < 9 ? p : (p < 9 + OC ? p - 9 : 0);
-    loff[i] = (unsigned)((size_t)ch * P * 4) + lc * 16;
+    loff[i] = (unsigned)((size_t)ch * A.ps * 4) + lc * 16;
   }
   // DEM piece j of this wave: chunk q = (wave + j NW) * 64 + lane of the (LH x 80) tile, row q / 20, column 4 (q % 20)
   int doff[C::DPW], dcx[C::DPW];
@@ -288,7 +289,7 @@ __global__ __launch_bounds__((SPLIT ? 2 : 1) * NW * 64, SPLIT ? 4 : 2) void prop
         char* gwb = reinterpret_cast<char*>(A.gweight + (size_t)b * A.wbs + pix);
         char* gob = reinterpret_cast<char*>(A.goffset + (size_t)b * A.obs + pix);
         const bool colok = x0 + sc * 4 < W;
-        const unsigned plane_b = (unsigned)(P * 4);
+        const unsigned plane_b = (unsigned)(A.ps * 4);
         // two batches (4 + 3 pieces): all seven lifted at once cost 28 registers the compute part has no room for
 #pragma unroll
         for (int i0 = 0; i0 < NOPIECE; i0 += 4) {
@@ -433,7 +434,7 @@ int prop_dma_forward(const float* dem, const float* weight, const float* offset,
                      float scale, float* out, int B, int H, int W, hipStream_t s) {
   DmaArgs A{};
   A.dem = dem; A.weight = weight; A.offset = offset; A.wk = wk; A.b0 = b0; A.out = out; A.scale = scale;
-  A.wbs = (size_t)9 * H * W; A.obs = (size_t)oc * H * W;
+  A.wbs = (size_t)9 * H * W; A.obs = (size_t)oc * H * W; A.ps = (size_t)H * W;
   const Plan p = make_plan(B, H, W, false, A);
   if (oc == 18) launch<18, false>(p, A, s); else launch<16, false>(p, A, s);
   return check_launch("prop_forward (dma)");
@@ -444,7 +445,7 @@ int prop_dma_backward(const float* gout, const float* dem, const float* weight, 
   DmaArgs A{};
   A.dem = dem; A.weight = weight; A.offset = offset; A.gout = gout; A.wk = wk; A.gweight = gweight; A.goffset = goffset;
   A.partial = partial;
-  A.wbs = (size_t)9 * H * W; A.obs = (size_t)oc * H * W;
+  A.wbs = (size_t)9 * H * W; A.obs = (size_t)oc * H * W; A.ps = (size_t)H * W;
   const Plan p = make_plan(B, H, W, true, A);
   if (oc == 18) launch<18, true>(p, A, s); else launch<16, true>(p, A, s);
   return check_launch("prop_backward (dma)");
@@ -455,8 +456,10 @@ int prop_dma_backward(const float* gout, const float* dem, const float* weight, 
 int prop_dma_logits_forward(const float* dem, const float* head, const float* wk, const float* b0, float scale, float* out,
                             int B, int H, int W, hipStream_t s) {
   DmaArgs A{};
-  A.dem = dem; A.weight = head; A.offset = head + (size_t)9 * H * W; A.wk = wk; A.b0 = b0; A.out = out; A.scale = scale;
-  A.wbs = A.obs = (size_t)25 * H * W;
+  static const int pad = env_int("JSPSR_LAB_PLANE_PAD", 0);      // lab: plane pitch H W + pad floats (the caller allocates accordingly)
+  A.ps = (size_t)H * W + pad;
+  A.dem = dem; A.weight = head; A.offset = head + 9 * A.ps; A.wk = wk; A.b0 = b0; A.out = out; A.scale = scale;
+  A.wbs = A.obs = 25 * A.ps;
   const Plan p = make_plan(B, H, W, false, A, false);
   if (p.ntl) launch4<16, false, 4, true, 1, true>(p, A, s); else launch4<16, false, 4, false, 1, true>(p, A, s);
   return check_launch("prop_logits_forward (dma)");
@@ -465,9 +468,11 @@ int prop_dma_logits_forward(const float* dem, const float* head, const float* wk
 int prop_dma_logits_backward(const float* gout, const float* dem, const float* head, const float* wk, float* ghead, float* partial,
                              int B, int H, int W, hipStream_t s) {
   DmaArgs A{};
-  A.dem = dem; A.weight = head; A.offset = head + (size_t)9 * H * W; A.gout = gout; A.wk = wk;
-  A.gweight = ghead; A.goffset = ghead + (size_t)9 * H * W; A.partial = partial;
-  A.wbs = A.obs = (size_t)25 * H * W;
+  static const int pad = env_int("JSPSR_LAB_PLANE_PAD", 0);
+  A.ps = (size_t)H * W + pad;
+  A.dem = dem; A.weight = head; A.offset = head + 9 * A.ps; A.gout = gout; A.wk = wk;
+  A.gweight = ghead; A.goffset = ghead + 9 * A.ps; A.partial = partial;
+  A.wbs = A.obs = 25 * A.ps;
   const Plan p = make_plan(B, H, W, true, A, false);
   if (p.ntl) launch4<16, true, 4, true, 1, true>(p, A, s); else launch4<16, true, 4, false, 1, true>(p, A, s);
   return check_launch("prop_logits_backward (dma)");
