@@ -1031,9 +1031,12 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
       // per CU stalls as a whole at each stage barrier; two 4-wave workgroups cover each other) -> opt-in only
       // (JSPSR_CONV_TALL=2).
       if (tall == 2 && tiles16 * ((g.Cout + 127) / 128) >= 512) return launch_patch<T, 256, 128, 4, 2>(in, wgt, bias, out, stats, g, s);
-      // lab (JSPSR_CONV_TALL=3): the 64-channel configuration's 16x16-pixel x 64-channel tile for wider layers too -- the patch
-      // is staged once per 64 output channels instead of once per 128, the weight tile once per 256 pixels instead of 128
-      if (tall == 3 && tiles16 * ((g.Cout + 63) / 64) >= 1024) return launch_patch<T, 256, 64, 4, 1>(in, wgt, bias, out, stats, g, s);
+      // round 4: the 64-channel configuration's 16x16-pixel x 64-channel tile for the wider layers too, once there are
+      // >= 1024 of them -- the patch is staged once per 64 output channels instead of once per 128, the weight tile once per
+      // 256 pixels instead of 128 (32 % fewer LDS write bytes per output): +3 % (8 x 512^2, 128 -> 128) .. +9.5 % (256 ->
+      // 256 data gradient at 128^2) per kernel, 67.03 -> 66.63 ms per single-stream step (profiles/r04_conv_tile_256x64_lab.txt).
+      // JSPSR_CONV_TALL=4 keeps the 128 x 128 tile of rounds 1-3.
+      if (tall && tall != 4 && tiles16 * ((g.Cout + 63) / 64) >= 1024) return launch_patch<T, 256, 64, 4, 1>(in, wgt, bias, out, stats, g, s);
       return launch_patch<T, 128, 128, 2, 2>(in, wgt, bias, out, stats, g, s);
     }
     if (g.Cout > 32) {
