@@ -122,6 +122,24 @@ int jspsr_prop_head_backward(int dtype, const float* grad_out, const float* dem,
                              void* grad_head, float* grad_wk, float* grad_b0, void* workspace, int B, int H, int W,
                              jspsr_stream_t stream);
 
+/* ---- K8: the steps either side of the model call, on device rasters -----------------------------
+ * jspsr_tiles_crop_f32: TileCrop's square cover, data/data_utils.py:87-194 -- x [C][H][W] -> out [n_x*n_x][C][k][k], tile
+ *   (r, c) = rows stride*r .., columns stride*c .., row-major over the cover.
+ * jspsr_tiles_merge_f32: merge_dem(method = copyto_add) with gen_weight_row / gen_weight_col, utils/utils.py:802-967 --
+ *   tiles [n_x*n_x][k][k] predictions, each first losing border_px pixels per side, weighted by the linear ramps over the
+ *   p = (k - 2 border_px) - stride pixels neighbours share (ramp [p] = linspace(1, 0, p + 2) without its ends, from the
+ *   caller) and summed into out [S][S], S = stride (n_x - 1) + k - 2 border_px.  Every mosaic pixel gathers its <= 4 tiles
+ *   in tile order: the same additions in the same order as the reference's tile-by-tile accumulation.
+ * jspsr_mirror_pad_f32: add_padding, utils/utils.py:1501-1520, index for index -- x [C][H][W] -> out [C][H+2n][W+2n].
+ * jspsr_elev_scale_f32: ToTensor.scale_data (descale = 0; data/data_utils.py:289-312: (z - base - min) / (max - min), or
+ *   log(z - base - min) / log(max - min) + 1e-8) and ToDEM.descale_data (descale = 1; data_utils.py:441-457). */
+int jspsr_tiles_crop_f32(const float* x, float* out, int C, int H, int W, int k, int stride, int n_x, jspsr_stream_t stream);
+int jspsr_tiles_merge_f32(const float* tiles, const float* ramp, float* out, int n_x, int k, int border_px, int stride,
+                          jspsr_stream_t stream);
+int jspsr_mirror_pad_f32(const float* x, float* out, int C, int H, int W, int n, jspsr_stream_t stream);
+int jspsr_elev_scale_f32(const float* in, float* out, long long n, int descale, int elev_log, double elev_min, double elev_max,
+                         double base_elev, jspsr_stream_t stream);
+
 /* ---- K1 in the models (round 4): logits + offsets as PLANES of one tensor ---------------------------------------
  * The same operator as jspsr_prop_forward_f32 / jspsr_prop_backward_f32 -- same kernels, same 108 / 208 algorithmic bytes
  * per pixel -- with what the reference does between the generator's heads and deform_conv2d folded in: the Sigmoid of

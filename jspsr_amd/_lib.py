@@ -71,6 +71,10 @@ SIGNATURES = {
     "jspsr_metrics_forward": (c_i, [c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_i, c_p, c_p, c_p]),
     "jspsr_adamw_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_i, c_p]),
     "jspsr_adamw_step_dev": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_p, c_p]),
+    "jspsr_tiles_crop_f32": (c_i, [c_p, c_p] + [c_i] * 6 + [c_p]),
+    "jspsr_tiles_merge_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "jspsr_mirror_pad_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "jspsr_elev_scale_f32": (c_i, [c_p, c_p, c_ll, c_i, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_p]),
     "jspsr_gate_mlp_forward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "jspsr_gate_mlp_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_gate_mlp_backward": (c_i, [c_p] * 7 + [c_i, c_i, c_i] + [c_p] * 6),

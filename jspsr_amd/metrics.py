@@ -17,8 +17,20 @@ import torch
 from . import _lib
 
 
+def _elev_hip(t, descale, elev_min, elev_max, elev_log, base_elev=0.0):
+    """fp32 device rasters: one HIP pass (csrc/tiles.hip, jspsr_elev_scale_f32)."""
+    t = t.contiguous()
+    out = torch.empty_like(t)
+    _lib.check(_lib.load().jspsr_elev_scale_f32(t.data_ptr(), out.data_ptr(), t.numel(), int(descale), int(bool(elev_log)), float(elev_min),
+                                                float(elev_max), float(base_elev), torch.cuda.current_stream().cuda_stream),
+               "jspsr_elev_scale_f32")
+    return out
+
+
 def scale_data(z, elev_min, elev_max, elev_log=False, base_elev=0.0):
     """metres -> network range (data_utils.py:289-312)."""
+    if z.is_cuda and z.dtype == torch.float32 and z.numel() and not z.requires_grad:
+        return _elev_hip(z, False, elev_min, elev_max, elev_log, base_elev)
     z = z - base_elev if base_elev != 0 else z
     if elev_log:
         return torch.log(z - elev_min) / log(elev_max - elev_min) + 1e-8
@@ -27,6 +39,8 @@ def scale_data(z, elev_min, elev_max, elev_log=False, base_elev=0.0):
 
 def descale_data(v, elev_min, elev_max, elev_log=False):
     """network range -> metres (data_utils.py:441-457)."""
+    if v.is_cuda and v.dtype == torch.float32 and v.numel() and not v.requires_grad:
+        return _elev_hip(v, True, elev_min, elev_max, elev_log)
     if elev_log:
         return torch.exp(v * log(elev_max - elev_min)) + elev_min
     return v * (elev_max - elev_min) + elev_min

@@ -13,6 +13,19 @@ from math import ceil
 
 import torch
 
+from . import _lib
+
+
+def _hip(t: torch.Tensor) -> bool:
+    """Device rasters in fp32 go through the HIP kernels (csrc/tiles.hip: jspsr_tiles_crop_f32 / _merge_f32,
+    jspsr_mirror_pad_f32); host tensors (the reference does all of this in numpy on the CPU) and other dtypes through the
+    same arithmetic as torch indexing -- index-for-index and, for the merge, bit-for-bit equal (tests/test_tiles_gpu.py)."""
+    return t.is_cuda and t.dtype == torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
 
 def get_tile(w: int, k: int, n: int | None = None):
     """(stride, number of tiles) of the square cover of a w-px side by k-px tiles; data_utils.py:170-194."""
@@ -30,6 +43,11 @@ def crop_tiles(x: torch.Tensor, k: int, n: int | None = None) -> torch.Tensor:
         return x[None]
     stride, n = get_tile(W, k, n)
     n_x = int(round(n ** 0.5))
+    if _hip(x):
+        x = x.contiguous()
+        out = torch.empty((n, C, k, k), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.load().jspsr_tiles_crop_f32(x.data_ptr(), out.data_ptr(), C, H, W, k, stride, n_x, _stream()), "jspsr_tiles_crop_f32")
+        return out
     return torch.stack([x[:, stride * r: stride * r + k, stride * c: stride * c + k]
                         for r in range(n_x) for c in range(n_x)])
 
@@ -59,6 +77,16 @@ def merge_tiles(tiles: torch.Tensor, full: int, border: float = 0.0) -> torch.Te
     w_h_c = full - (k - w_l_c)
     s, n2 = get_tile(w_h_c, w_l_c)
     assert n2 == n
+    if _hip(tiles):
+        if n_x not in (2, 3):
+            raise NotImplementedError(f"n {n} is not 9 or 4")
+        p = w_l_c - s
+        ramp = torch.linspace(1, 0, p + 2, dtype=torch.float64)[1:-1].to(device=tiles.device, dtype=torch.float32).contiguous()
+        tiles = tiles.contiguous()
+        out = torch.empty((w_h_c, w_h_c), dtype=tiles.dtype, device=tiles.device)
+        _lib.check(_lib.load().jspsr_tiles_merge_f32(tiles.data_ptr(), ramp.data_ptr() if p > 0 else None, out.data_ptr(), n_x, k, b, s,
+                                                     _stream()), "jspsr_tiles_merge_f32")
+        return out
     out = torch.zeros((w_h_c, w_h_c), dtype=tiles.dtype, device=tiles.device)
     for i in range(n):
         r, c = divmod(i, n_x)
@@ -89,6 +117,11 @@ def add_padding(x: torch.Tensor, n: int) -> torch.Tensor:
     if n == 0:
         return x
     C, H, W = x.shape
+    if _hip(x) and n < H and n <= W:
+        x = x.contiguous()
+        o = torch.empty((C, H + 2 * n, W + 2 * n), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.load().jspsr_mirror_pad_f32(x.data_ptr(), o.data_ptr(), C, H, W, n, _stream()), "jspsr_mirror_pad_f32")
+        return o
     o = torch.empty((C, H + 2 * n, W + 2 * n), dtype=x.dtype, device=x.device)
     o[:, n:n + H, n:n + W] = x
     o[:, n:n + H, :n] = x[:, :, :n].flip(2)

@@ -161,7 +161,10 @@ def test_init_stream_equals_reference(golden_dir, name):
     for i, k in enumerate(sd):
         t = sd[k].double().reshape(-1)
         got = np.array([t.sum().item(), t.abs().sum().item(), t[0].item(), t[-1].item()])
-        assert np.array_equal(got, z["summary"][i]), k
+        # first / last element exactly; the two sums to the last bits a double sum's ORDER can move (torch's parallel
+        # reduction splits the tensor by thread count: 8 threads where the fixture was made, 16 on a GPU box)
+        assert np.array_equal(got[2:], z["summary"][i][2:]), k
+        assert np.allclose(got[:2], z["summary"][i][:2], rtol=0, atol=1e-12 * got[1]), k
 
 
 @pytest.mark.gpu
