@@ -140,6 +140,27 @@ def time_k1(model, inputs, iters=20):
     # the names reported below are the kernels this process launched: the launch census must have moved
     logits_dma = (census("prop_logits_forward (dma)") - c0[0] == 3 * (300 + iters) and
                   census("prop_logits_backward (dma)") - c0[1] == 3 * (300 + iters))
+    # The same two launches with the Infinity Cache (256 MB) out of the picture: SIXTEEN operand sets (3.4 GB of operands,
+    # 3.4 GB of gradients) instead of four.  Four rotating sets -- what rounds 1-3 timed, kept above for comparability --
+    # still find part of their lines in the cache (its replacement is not LRU: same kernel, same box, 84-85 us with four
+    # sets, 88 us with eight, placement-dependent); inside the running step the operands are cold (the head planes were
+    # written ~30 ms earlier), so `cold` is the figure that describes the kernel in the model.
+    ncold = 16
+    lsets += [torch.cat((1.5 * torch.randn(B, 9, H, W, device=dev, generator=g), 1.5 * torch.randn(B, 16, H, W, device=dev, generator=g)), 1)
+              for _ in range(ncold - nset)]
+    glsets += [torch.empty_like(lsets[0]) for _ in range(ncold - nset)]
+
+    def lfwd_cold(i):
+        _lib.check(lib.jspsr_prop_logits_forward_f32(dem.data_ptr(), lsets[i % ncold].data_ptr(), w.data_ptr(), b.data_ptr(), 1.0,
+                                                     out.data_ptr(), B, H, W, st()), "jspsr_prop_logits_forward_f32")
+
+    def lbwd_cold(i):
+        _lib.check(lib.jspsr_prop_logits_backward_f32(gout.data_ptr(), dem.data_ptr(), lsets[i % ncold].data_ptr(), w.data_ptr(),
+                                                      glsets[i % ncold].data_ptr(), None, None, ws.data_ptr(), B, H, W, st()),
+                   "jspsr_prop_logits_backward_f32")
+
+    for name, fn in (("lfwd_cold", lfwd_cold), ("lbwd_cold", lbwd_cold)):
+        res[name], reps[name] = timed(fn)
     del lsets, glsets
     # K1c: the heads themselves (csrc/head.hip) on the generator's 128-channel feature in the model's storage dtype
     hdt = model.compute_dtype
@@ -260,6 +281,12 @@ def time_k1(model, inputs, iters=20):
                     "traffic": tr("logits_fwd_bytes_per_launch"), "bytes_per_launch": fb,
                     "us_per_launch": round(res["lfwd"] * 1e6, 2), "us_per_launch_reps": reps["lfwd"]},
         "kernel_in_model": True, "launch_census_checked": bool(logits_dma),
+        "cold": {"operand_sets": 16, "us_per_launch": round(res["lbwd_cold"] * 1e6, 2), "us_per_launch_reps": reps["lbwd_cold"],
+                 "achieved": gbs(bb, res["lbwd_cold"]), "frac": frac(bb, res["lbwd_cold"]),
+                 "forward": {"us_per_launch": round(res["lfwd_cold"] * 1e6, 2), "us_per_launch_reps": reps["lfwd_cold"],
+                             "achieved": gbs(fb, res["lfwd_cold"]), "frac": frac(fb, res["lfwd_cold"])},
+                 "note": "the same launches rotating over 16 operand sets (3.4 GB + 3.4 GB of gradients): no help from the 256 MB "
+                         "Infinity Cache -- the state the kernel is in inside the running step, where its operands are cold"},
         "public_boundary": public, "head_conv": head_conv, "legacy_nhwc_head": legacy, "steps_entry": steps_entry,
         "note": "top level = the propagation kernel THE BENCHMARKED STEP LAUNCHES for spn.py:43,69-73,99-118 (jspsr_prop_logits_*: "
                 "planar fp32 logits + offsets written by the generator's heads, sigmoid inside; backward in the top-level keys, "

@@ -20,8 +20,12 @@ out = torch.empty_like(dem)
 w, b = torch.ones(9, device=dev), torch.zeros(1, device=dev)
 ps = H * W + pad
 nset = 8
+shift = int(os.environ.get("K1_LAB_SHIFT_KB", "0"))
+dummy = torch.empty(max(shift, 1) * 256, device=dev) if shift else None       # moves every later allocation by `shift` KiB
+nset = int(os.environ.get("K1_LAB_NSET", str(nset)))
 heads = [1.5 * torch.randn(B * 25 * ps, device=dev, generator=g) for _ in range(nset)]
-gheads = [torch.empty_like(t) for t in heads]
+print("head addresses mod 2 MiB (KiB):", [h.data_ptr() % (2 << 20) // 1024 for h in heads[:4]], "mod 1 GiB (MiB):", [h.data_ptr() % (1 << 30) >> 20 for h in heads[:4]], flush=True)
+gheads = heads if os.environ.get("K1_LAB_INPLACE") == "1" else [torch.empty_like(t) for t in heads]
 ws = ops.prop_backward_workspace(B, H, W, dev)
 st = lambda: torch.cuda.current_stream().cuda_stream
 lf = lambda i: _lib.check(lib.jspsr_prop_logits_forward_f32(dem.data_ptr(), heads[i % nset].data_ptr(), w.data_ptr(), b.data_ptr(), 1.0, out.data_ptr(), B, H, W, st()), "lf")
