@@ -246,11 +246,20 @@ int jspsr_conv2d_forward(int dtype, const void* in, const void* wpack, const flo
  * gin = [relu](...) + addend.  It carries the gradient that reaches the same tensor along another path (the
  * residual branch of a BasicBlock, basics.py:113-122), which autograd would otherwise add in a separate pass.
  * scale (may be NULL): per-channel factor as in jspsr_conv2d_forward -- ConvTranspose2d -> BatchNorm(eval) -> ReLU
- * of the decoder (basics.py:69-85) in one launch at inference.  gin = [relu](acc * scale + bias + addend). */
+ * of the decoder (basics.py:69-85) in one launch at inference.  gin = [relu](acc * scale + bias + addend).
+ * red_x / red_cstride / red_par / red_out (round 4; all NULL / 0: off): the REDUCE pass of the BatchNorm whose output
+ * gradient this launch produces (conv -> BN -> ReLU -> conv of BasicBlock, basics.py:111-117: gin is the gradient of the
+ * ReLU's output), taken in the epilogue instead of by a pass of its own.  red_x: that BatchNorm's saved input on gin's grid
+ * (Cin channels at pitch red_cstride); red_par [4][Cin] from jspsr_bn_reduce_params; red_out: partial rows
+ * [jspsr_conv2d_stats_rows(B, IH, IW)][2][Cin] = per 8x16-pixel tile the sums of dz and dz * xhat, dz = the stored gin where
+ * the ReLU was open -- handed to jspsr_bn_backward as ext_partial.  Available where
+ * jspsr_conv2d_dgrad_reduce_ok(...) != 0 (3x3, stride 1, pad 1 on the patch kernel). */
+int jspsr_conv2d_dgrad_reduce_ok(int dtype, int B, int IH, int IW, int Cg, int Cin, int KH, int KW, int stride, int pad);
 int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,
                        int B, int OH, int OW, int Cg, int g_cstride, int g_coff, int IH, int IW,
                        int Cin, int in_cstride, int in_coff, int KH, int KW, int stride, int pad,
-                       int relu, const void* addend, int add_cstride, const float* scale, jspsr_stream_t stream);
+                       int relu, const void* addend, int add_cstride, const float* scale,
+                       const void* red_x, int red_cstride, const float* red_par, float* red_out, jspsr_stream_t stream);
 
 /* Weight gradient (autograd of nn.Conv2d / nn.ConvTranspose2d w.r.t. .weight):
  *   dW[r][c][ky][kx] = sum_{b,oy,ox} G[b,oy,ox,r] * X[b, oy*stride-pad+ky, ox*stride-pad+kx, c]
@@ -306,12 +315,16 @@ int jspsr_bn_fold(const float* gamma, const float* beta, const float* running_me
  * (y > 0); 2 = mask recomputed from x as gamma*xhat + beta > 0 (valid without a residual; y is not read).
  * dx (dense, pitch C) = grad w.r.t. x; dres (dense, may be NULL) = grad w.r.t. res;
  * dgamma, dbeta [C]: overwritten, or added to when accumulate != 0 (gradients landing directly in a
- * caller-owned accumulation buffer). */
+ * caller-owned accumulation buffer).
+ * ext_partial / ext_rows (NULL / 0: this call makes its own reduce pass): the per-tile sums of dz and dz * xhat, rows of
+ * [2][C], that the producing data gradient's epilogue wrote (jspsr_conv2d_dgrad: red_out) -- relu mode 2 only. */
+int jspsr_bn_reduce_params(const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int C,
+                           float* par, jspsr_stream_t stream);
 int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
                       const void* x, int x_cs, int x_coff, const float* gamma, const float* beta, const float* save_mean,
                       const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
                       float* dgamma, float* dbeta, int accumulate, long long npix, int C, void* workspace,
-                      jspsr_stream_t stream);
+                      const float* ext_partial, int ext_rows, jspsr_stream_t stream);
 
 /* Backward of the conv epilogue `y = [relu](conv + bias)` of the BN-free Basic2d (basics.py:36-53):
  * dz = dy * [y > 0] (y read with channel pitch y_cs; dz written with pitch dz_cs if dz != NULL),

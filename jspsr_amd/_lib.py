@@ -50,15 +50,17 @@ SIGNATURES = {
     "jspsr_conv2d_in_affine_ok": (c_i, [c_i] * 5),
     "jspsr_conv2d_forward": (c_i, [c_i] + [c_p] * 4 + [c_i] * 14 + [c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "jspsr_bn_fold": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p]),
-    "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p, c_i, c_p, c_p]),
+    "jspsr_conv2d_dgrad_reduce_ok": (c_i, [c_i] * 10),
+    "jspsr_conv2d_dgrad": (c_i, [c_i] + [c_p] * 4 + [c_i] * 16 + [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
     "jspsr_conv2d_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i] * 8),
     "jspsr_conv2d_wgrad_x_affine_ok": (c_i, [c_i] * 10),
     "jspsr_conv2d_wgrad": (c_i, [c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p] + [c_i] * 12 + [c_p, c_i, c_p, c_p]),
     "jspsr_reduce_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "jspsr_bn_forward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_i,
                                c_i, c_f, c_p, c_p, c_ll, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "jspsr_bn_reduce_params": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "jspsr_bn_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_f,
-                                c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p]),
+                                c_p, c_p, c_p, c_p, c_i, c_ll, c_i, c_p, c_p, c_i, c_p]),
     "jspsr_act_backward": (c_i, [c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_ll, c_i, c_p, c_p]),
     "jspsr_gate_pool": (c_i, [c_i, c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_p]),
     "jspsr_gate_scale": (c_i, [c_i, c_p, c_p, c_p, c_i, c_ll, c_i, c_p]),

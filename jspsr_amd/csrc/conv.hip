@@ -126,6 +126,22 @@ __device__ __forceinline__ void stats_epilogue(const typename M::acc_t (&acc)[MI
   __syncthreads();
 }
 
+// 16 bytes of T -> EPC floats
+template <typename T>
+__device__ __forceinline__ void unpack_chunk(const uint4& v, float (&f)[Elem<T>::EPC]) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(w[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+}
+
 // 16 bytes of T plus 16 bytes of T, element-wise (fp32 add, one rounding): the epilogue's `+ addend`
 template <typename T>
 __device__ __forceinline__ uint4 add_packed(uint4 a, uint4 b) {
@@ -859,6 +875,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
     // profiles/r03_conv_patch_wave_life.txt).
     long long ooff[OB];        // byte offset from obase, -1: nothing to store (outside the written grid / beyond Cout)
     uint4 areg[OB];
+    uint4 zreg[OB];            // BatchNorm-backward reduce (g.red_out): the saved pre-normalisation values of the pieces
     // Beside a partner wave that keeps the matrix pipe busy a vector instruction of this wave costs ~10 cycles, so the
     // per-piece arithmetic is kept short: the tile's origin on the written grid and its byte offset are wave-uniform
     // (scalar unit, 64-bit), a piece adds a 32-bit pixel delta by one v_mad_u64_u32, and the bounds tests are skipped
@@ -867,6 +884,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
     const long long pix_t = ((long long)bimg * g.OH + oy_t) * g.OW + ox_t;
     const unsigned ocs = (unsigned)g.out_cstride * (unsigned)sizeof(T), acs = (unsigned)g.add_cstride * (unsigned)sizeof(T);
     const long long obase_t = pix_t * ocs, abase_t = pix_t * acs + n0 * (long long)sizeof(T);
+    const unsigned zcs = (unsigned)g.red_cstride * (unsigned)sizeof(T);
+    const long long zbase_t = pix_t * zcs + n0 * (long long)sizeof(T);
     const bool inside = ty0 + TLH <= g.MH && tx0 + TLW <= g.MW && oy_t + (TLH - 1) * g.oy_mul < g.OH &&
                         ox_t + (TLW - 1) * g.ox_mul < g.OW && n0 + BN <= g.Cout;
     auto plan_pieces = [&](int j0) __attribute__((always_inline)) {
@@ -886,8 +905,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
             areg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.addend) + abase_t +
                                                       (long long)((unsigned long long)dpix * acs) + c16 * 16);
         }
+        if (g.red_out) {
+          zreg[j] = make_uint4(0, 0, 0, 0);
+          if (ok)
+            zreg[j] = *reinterpret_cast<const uint4*>(static_cast<const char*>(g.red_x) + zbase_t +
+                                                      (long long)((unsigned long long)dpix * zcs) + c16 * 16);
+        }
       }
     };
+    // BatchNorm-backward reduce: this thread's pieces all hold the same EPC channels (NTH is a multiple of the pieces per
+    // row), so their two sums live in registers across the copy loop -- the accumulators are dead by then
+    float rs1[EPC], rs2[EPC], rpa[EPC], rpb[EPC], rpi[EPC], rpm[EPC];
+    if (g.red_out) {
+      static_assert(NTH % CPRO == 0, "a thread's pieces share their channels");
+      const int cc = n0 + (tid % CPRO) * EPC;
+#pragma unroll
+      for (int e2 = 0; e2 < EPC; ++e2) {
+        const bool in_c = cc + e2 < g.Cout;
+        rs1[e2] = rs2[e2] = 0.f;
+        rpa[e2] = in_c ? g.red_par[cc + e2] : 0.f;
+        rpb[e2] = in_c ? g.red_par[g.Cout + cc + e2] : 0.f;
+        rpi[e2] = in_c ? g.red_par[2 * g.Cout + cc + e2] : 0.f;
+        rpm[e2] = in_c ? g.red_par[3 * g.Cout + cc + e2] : 0.f;
+      }
+    }
     plan_pieces(0);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -922,6 +963,43 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN == 8 ? 1 : 2) void conv_p
         if (g.addend) v = add_packed<T>(v, areg[j]);
         if (relu_last) v = relu_packed<T>(v);
         *reinterpret_cast<uint4*>(obase + ooff[j]) = v;
+        if (g.red_out) {      // dz = the stored gradient where the ReLU behind the BatchNorm was open; sums of dz and dz * xhat
+          float dv[EPC], zv[EPC];
+          unpack_chunk<T>(v, dv);
+          unpack_chunk<T>(zreg[j], zv);
+#pragma unroll
+          for (int e2 = 0; e2 < EPC; ++e2) {
+            const float dz = rpa[e2] * zv[e2] + rpb[e2] > 0.f ? dv[e2] : 0.f;
+            rs1[e2] += dz;
+            rs2[e2] += dz * (zv[e2] * rpi[e2] + rpm[e2]);
+          }
+        }
+      }
+    }
+    if (g.red_out) {
+      // fold over the NTH / CPRO threads that share a channel group (fixed order), one partial row per 8x16-pixel tile
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);      // [NTH][2 EPC]
+#pragma unroll
+      for (int e2 = 0; e2 < EPC; ++e2) {
+        red[tid * 2 * EPC + e2] = rs1[e2];
+        red[tid * 2 * EPC + EPC + e2] = rs2[e2];
+      }
+      __syncthreads();
+      int r1 = mt, r2 = -1;
+      if constexpr (BM != 128) {
+        const int tty8 = (g.MH + 7) / 8;
+        r1 = (bimg * tty8 + 2 * tyi) * ttx + txi;
+        r2 = (2 * tyi + 1 < tty8) ? r1 + ttx : -1;
+      }
+      for (int i = tid; i < 2 * BN; i += NTH) {
+        const int which = i / BN, col = i % BN;
+        if (n0 + col >= g.Cout) continue;
+        const int cg_ = col / EPC, e2 = col % EPC;
+        float tsum = 0.f;
+        for (int k2 = 0; k2 < NTH / CPRO; ++k2) tsum += red[(cg_ + CPRO * k2) * 2 * EPC + which * EPC + e2];
+        g.red_out[((size_t)r1 * 2 + which) * g.Cout + n0 + col] = tsum;
+        if (r2 >= 0) g.red_out[((size_t)r2 * 2 + which) * g.Cout + n0 + col] = 0.f;
       }
     }
   } else {
@@ -1047,6 +1125,7 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
     }
     return launch_patch<T, 128, 32, 4, 1>(in, wgt, bias, out, stats, g, s);
   }
+  if (g.red_out) return fail(JSPSR_EINVAL, "conv2d_dgrad: the fused BatchNorm-backward reduce needs the patch kernel (jspsr_conv2d_dgrad_reduce_ok)");
   if (g.in_affine) return fail(JSPSR_EINVAL, "conv2d_forward: in_affine needs the patch kernel (stride 1, 2..9 taps, Cin a multiple of %d): ask jspsr_conv2d_in_affine_ok first", BKT);
   static const int nbuf_env = [] { const char* e = getenv("JSPSR_CONV_NBUF"); return e ? atoi(e) : 0; }();
   const int nbuf_narrow = nbuf_env ? nbuf_env : ((long long)g.nty * g.ntx * g.Cin <= 1152 ? 1 : 2);
@@ -1188,13 +1267,42 @@ extern "C" int jspsr_conv2d_in_affine_ok(int dtype, int Cin, int KH, int KW, int
          Cin > 0 && Cin % bk == 0;
 }
 
+// Can the data gradient of this conv carry the reduce pass of the BatchNorm behind its input (ConvGeom::red_*)?  The patch
+// kernel's 16-byte epilogue does: 3x3, stride 1, pad 1, gathered channels a multiple of the stage depth, written channels
+// whole 16-byte chunks -- and only where the launch would take the patch kernel anyway (the 64 -> 64 bf16 layers on >= 512
+// tiles go to K2r, whose register budget has no room for the sums: DESIGN.md section 5).
+extern "C" int jspsr_conv2d_dgrad_reduce_ok(int dtype, int B, int IH, int IW, int Cg, int Cin, int KH, int KW, int stride, int pad) {
+  if (dtype != JSPSR_F32 && dtype != JSPSR_BF16) return 0;
+  static const int off = [] { const char* e = getenv("JSPSR_BN_REDUCE_FUSE"); return e && atoi(e) == 0; }();
+  if (off) return 0;
+  const int epc = dtype == JSPSR_F32 ? 4 : 8, bkt = NCH * epc;
+  if (KH != 3 || KW != 3 || stride != 1 || pad != 1 || Cg <= 0 || Cg % bkt || Cin <= 0 || Cin % epc || B <= 0 || IH <= 0 || IW <= 0) return 0;
+  static const int no_patch = [] { const char* e = getenv("JSPSR_CONV_NOPATCH"); return e ? atoi(e) : 0; }();
+  if (no_patch) return 0;
+  if (dtype == JSPSR_BF16 && Cg == 64 && Cin == 64) {
+    static const int resident = [] { const char* e = getenv("JSPSR_CONV_RESIDENT"); return e ? atoi(e) : 1; }();
+    static const int min_tiles = [] { const char* e = getenv("JSPSR_CONV_RESIDENT_MIN"); return e ? atoi(e) : 512; }();
+    if (resident && (long long)B * ((IH + 15) / 16) * ((IW + 15) / 16) >= min_tiles) return 0;
+  }
+  return 1;
+}
+
 extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack_t, const float* bias, void* gin,
                                   int B, int OH, int OW, int Cg, int g_cstride, int g_coff, int IH, int IW,
                                   int Cin, int in_cstride, int in_coff, int KH, int KW, int stride, int pad,
                                   int relu, const void* addend, int add_cstride, const float* scale,
+                                  const void* red_x, int red_cstride, const float* red_par, float* red_out,
                                   jspsr_stream_t stream) {
   if (int e = check_common(dtype, gout, wpack_t, gin, Cg, g_cstride, g_coff, in_cstride, in_coff, Cin, "conv2d_dgrad")) return e;
   if (addend && add_cstride < Cin) return fail(JSPSR_EINVAL, "conv2d_dgrad: addend pitch %d < %d channels", add_cstride, Cin);
+  if (red_out) {
+    if (!red_x || !red_par || !jspsr_conv2d_dgrad_reduce_ok(dtype, B, IH, IW, Cg, Cin, KH, KW, stride, pad))
+      return fail(JSPSR_EINVAL, "conv2d_dgrad: the fused BatchNorm-backward reduce needs jspsr_conv2d_dgrad_reduce_ok(...) != 0");
+    const int epc = dtype == JSPSR_F32 ? 4 : 8;
+    if (red_cstride < Cin || red_cstride % epc || in_cstride % epc || in_coff % epc || !aligned16(red_x) || !aligned16(gin) ||
+        (addend && (!aligned16(addend) || add_cstride % epc)))
+      return fail(JSPSR_EALIGN, "conv2d_dgrad: fused reduce needs 16-byte pieces (pitches / offsets multiples of %d, aligned tensors)", epc);
+  }
   if (B <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     return fail(JSPSR_EINVAL, "conv2d_dgrad: bad geometry");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1217,6 +1325,7 @@ extern "C" int jspsr_conv2d_dgrad(int dtype, const void* gout, const void* wpack
       g.sign = -1; g.KH = KH; g.KW = KW;
       g.oy_mul = stride; g.oy_add = py; g.ox_mul = stride; g.ox_add = px; g.relu = relu;
       g.addend = addend; g.add_cstride = add_cstride; g.scale = scale;
+      g.red_x = red_x; g.red_cstride = red_cstride; g.red_par = red_par; g.red_out = red_out;
       const int e = dtype == JSPSR_F32 ? launch<float>(gout, wpack_t, bias, gin, nullptr, g, s)
                                        : launch<__bf16>(gout, wpack_t, bias, gin, nullptr, g, s);
       if (e) return e;

@@ -602,7 +602,7 @@ bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, cons
   if (!enabled) return false;
   if (g.Cin != 64 || g.Cout != 64 || g.nty != 3 || g.ntx != 3 || g.KH != 3 || g.KW != 3) return false;
   if (g.iy_mul != 1 || g.ix_mul != 1 || g.oy_mul != 1 || g.ox_mul != 1 || g.oy_add != 0 || g.ox_add != 0) return false;
-  if (g.ky0 != 0 || g.kx0 != 0 || g.kstep != 1 || g.in_affine) return false;
+  if (g.ky0 != 0 || g.kx0 != 0 || g.kstep != 1 || g.in_affine || g.red_out) return false;
   if (g.in_cstride % 8 || g.in_coff % 8 || g.out_cstride % 8 || g.out_coff % 8) return false;
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;

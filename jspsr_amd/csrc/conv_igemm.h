@@ -51,6 +51,16 @@ struct ConvGeom {
   const float* in_affine; // optional [2][Cin] (scale | shift): the gathered tensor is read as [relu](x * scale + shift),
   int in_relu;            // applied while the patch is staged (patch kernel only); zero padding stays zero
   FastDiv fd_ntn, fd_ttx, fd_tty;   // patch kernel: division by its N-tile / tile-column / tile-row counts (set by its launcher)
+  // Round 4 -- the reduce pass of a BatchNorm backward in the epilogue of the data gradient that PRODUCES its input gradient
+  // (patch kernel, 16-byte epilogue path): red_x = the BatchNorm's saved pre-normalisation tensor on the written grid (channel
+  // pitch red_cstride, channel 0 = channel out_coff of the written slice... of ITS OWN tensor: first channel 0), red_par =
+  // [4][Cout] floats (a | b | is | mis: mask = a z + b > 0, xhat = z is + mis), red_out = partial rows
+  // [jspsr_conv2d_stats_rows][2][Cout]: sum dz and sum dz xhat over each 8x16-pixel tile, dz = the STORED gradient where the
+  // ReLU was open.  NULL: off.
+  const void* red_x;
+  int red_cstride;
+  const float* red_par;
+  float* red_out;
 };
 
 // K2r (conv64.hip): 3x3 64->64 unit-stride bf16 conv / data gradient, weights resident in registers

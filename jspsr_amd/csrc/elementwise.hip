@@ -762,11 +762,32 @@ extern "C" int jspsr_bn_forward(int dtype, const void* x, int x_cs, int x_coff, 
   return check_launch("bn_apply");
 }
 
+// par [4][C] = a | b | is | mis for the reduce fused into a data-gradient epilogue (ConvGeom::red_par): the ReLU behind the
+// BatchNorm was open where a z + b > 0 (a = gamma invstd, b = beta - gamma invstd mean), xhat = z is + mis
+__global__ void bn_reduce_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                        const float* __restrict__ invstd, int C, float* __restrict__ par) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float a = gamma[c] * invstd[c];
+  par[c] = a;
+  par[C + c] = beta[c] - a * mean[c];
+  par[2 * C + c] = invstd[c];
+  par[3 * C + c] = -mean[c] * invstd[c];
+}
+
+extern "C" int jspsr_bn_reduce_params(const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int C,
+                                      float* par, jspsr_stream_t stream) {
+  if (!gamma || !beta || !save_mean || !save_invstd || !par || C <= 0) return fail(JSPSR_EINVAL, "bn_reduce_params: bad arguments");
+  hipLaunchKernelGGL(bn_reduce_params_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gamma, beta,
+                     save_mean, save_invstd, C, par);
+  return check_launch("bn_reduce_params");
+}
+
 extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_coff, const void* y, int y_cs, int y_coff,
                                  const void* x, int x_cs, int x_coff, const float* gamma, const float* beta, const float* save_mean,
                                  const float* save_invstd, int training, int relu, float res_scale, void* dx, void* dres,
                                  float* dgamma, float* dbeta, int accumulate, long long npix, int C, void* workspace,
-                                 jspsr_stream_t stream) {
+                                 const float* ext_partial, int ext_rows, jspsr_stream_t stream) {
   if (int e = check_c(dtype, C, "bn_backward")) return e;
   if (!dy || !x || !gamma || !save_mean || !save_invstd || !dx || !dgamma || !dbeta || !workspace || npix <= 0 ||
       (relu == 1 && !y) || (relu == 2 && !beta) || relu < 0 || relu > 2)
@@ -782,10 +803,25 @@ extern "C" int jspsr_bn_backward(int dtype, const void* dy, int dy_cs, int dy_co
 #define BN_BWD_REDUCE(R) DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R>), red_grid(g, vec), dim3(TX, TY), 0, s, \
                                      static_cast<const T*>(dy), dy_cs, dy_coff, static_cast<const T*>(y), y_cs, y_coff,     \
                                      static_cast<const T*>(x), x_cs, x_coff, save_mean, save_invstd, gamma, beta, g, partial))
-  if (relu == 0) { BN_BWD_REDUCE(0); } else if (relu == 1) { BN_BWD_REDUCE(1); } else { BN_BWD_REDUCE(2); }
+  int rows = g.chunks;
+  if (ext_partial) {
+    // the two sums per channel came out of the producing data gradient's epilogue (jspsr_conv2d_dgrad: red_out), one row
+    // per 8x16-pixel tile: no reduce pass here; many rows are folded to <= 1024 first (fixed order), as the forward does
+    if (ext_rows <= 0) return fail(JSPSR_EINVAL, "bn_backward: ext_rows must be positive");
+    if (ext_rows > 1024) {
+      rows = g.chunks < 1024 ? (g.chunks > 0 ? g.chunks : 1) : 1024;
+      hipLaunchKernelGGL(fold_rows_kernel, dim3(rows, (2 * C + 255) / 256), dim3(256), 0, s, ext_partial, ext_rows, 2 * C, rows, partial);
+      if (int e = check_launch("bn_fold_rows")) return e;
+    } else {
+      partial = const_cast<float*>(ext_partial);
+      rows = ext_rows;
+    }
+  } else {
+    if (relu == 0) { BN_BWD_REDUCE(0); } else if (relu == 1) { BN_BWD_REDUCE(1); } else { BN_BWD_REDUCE(2); }
+    if (int e = check_launch("bn_bwd_reduce")) return e;
+  }
 #undef BN_BWD_REDUCE
-  if (int e = check_launch("bn_bwd_reduce")) return e;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, g.chunks, C, npix, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, rows, C, npix, gamma,
                      save_invstd, training, res_scale, accumulate, dgamma, dbeta, coef);
   if (int e = check_launch("bn_bwd_finalize")) return e;
 #define BN_BWD_APPLY(R) DISPATCH(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), red_grid(g, vec), dim3(TX, TY), 0, s,  \

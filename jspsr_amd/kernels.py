@@ -122,8 +122,23 @@ def conv2d_forward(x, wpack, bias, stride, pad, relu=False, out=None, out_coff=0
     return (out, st) if stats else out
 
 
+def dgrad_reduce_ok(dtype, B, IH, IW, Cg, Cin, KH, KW, stride, pad) -> bool:
+    """Can this data gradient carry the reduce pass of the BatchNorm behind its input (conv2d_dgrad(red=...))?"""
+    dt = F32 if dtype == torch.float32 else BF16
+    return bool(_lib.load().jspsr_conv2d_dgrad_reduce_ok(dt, B, IH, IW, Cg, Cin, KH, KW, stride, pad))
+
+
+def bn_reduce_params(gamma, beta, mean, invstd):
+    """[4][C] fp32 (a | b | is | mis) for conv2d_dgrad(red=...): mask = a z + b > 0, xhat = z is + mis."""
+    C = gamma.numel()
+    par = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    _lib.check(_lib.load().jspsr_bn_reduce_params(gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(), C,
+                                                  par.data_ptr(), _stream()), "jspsr_bn_reduce_params")
+    return par
+
+
 def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None, out_coff=0, g_coff=0, addend=None,
-                 scale=None):
+                 scale=None, red=None):
     """g (B,OH,OW,Cgs) NHWC, wpack_t [Cin][KH][KW][Cg] -> (B,IH,IW,Cin): data gradient of a conv /
     forward of a transposed conv.  addend (B,IH,IW,Cin): added in the epilogue (a gradient arriving along
     another path)."""
@@ -143,14 +158,27 @@ def conv2d_dgrad(g, wpack_t, in_hw, stride, pad, bias=None, relu=False, out=None
         if tuple(addend.shape) != (B, IH, IW, Cin) or addend.dtype != g.dtype:
             raise ValueError(f"conv2d_dgrad: addend {tuple(addend.shape)} {addend.dtype} does not match the result")
     lib = _lib.load()
+    red_x = red_par = red_out = None
+    if red is not None:
+        # red = (x, par): the BatchNorm's saved input on the result's grid and jspsr_bn_reduce_params' table -> the partial
+        # rows of its backward reduce come back beside the result
+        red_x, red_par = red
+        _chk_s(red_x, "conv2d_dgrad red_x")
+        if tuple(red_x.shape) != (B, IH, IW, Cin) or red_x.dtype != g.dtype:
+            raise ValueError(f"conv2d_dgrad: red_x {tuple(red_x.shape)} {red_x.dtype} does not match the result")
+        rows = lib.jspsr_conv2d_stats_rows(B, IH, IW)
+        red_out = torch.empty((rows, 2, Cin), dtype=torch.float32, device=g.device)
     _lib.check(lib.jspsr_conv2d_dgrad(_dt(g), g.data_ptr(), wpack_t.data_ptr(),
                                       bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                       B, OH, OW, Cg, Cgs, g_coff, IH, IW, Cin, pitch(out), out_coff,
                                       KH, KW, stride, pad, int(relu),
                                       addend.data_ptr() if addend is not None else None,
                                       pitch(addend) if addend is not None else 0,
-                                      scale.data_ptr() if scale is not None else None, _stream()), "jspsr_conv2d_dgrad")
-    return out
+                                      scale.data_ptr() if scale is not None else None,
+                                      red_x.data_ptr() if red is not None else None, pitch(red_x) if red is not None else 0,
+                                      red_par.data_ptr() if red is not None else None,
+                                      red_out.data_ptr() if red is not None else None, _stream()), "jspsr_conv2d_dgrad")
+    return (out, red_out) if red is not None else out
 
 
 def conv2d_wgrad(G, X, R, C, KH, KW, stride, pad, out=None, accumulate=False, g_coff=0, cg=None, x_coff=0, cx=None,
@@ -239,7 +267,7 @@ def bn_fold(gamma, beta, running_mean, running_var, eps, res_scale=1.0):
 
 
 def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, want_dres=False, beta=None,
-                grads_into=None):
+                grads_into=None, ext_partial=None):
     """-> (dx, dres or None, dgamma, dbeta).  relu: False/0, True/1 (mask from y) or 2 (mask from x, needs beta).
     grads_into = (dgamma_buf, dbeta_buf): add the parameter gradients to those fp32 buffers instead of
     returning fresh tensors (then dgamma, dbeta come back as None)."""
@@ -264,6 +292,8 @@ def bn_backward(dy, y, x, gamma, mean, invstd, training, relu, res_scale=1.0, wa
                                      mean.data_ptr(), invstd.data_ptr(), int(training), int(relu), float(res_scale),
                                      dx.data_ptr(), dres.data_ptr() if dres is not None else None, dgamma.data_ptr(),
                                      dbeta.data_ptr(), int(grads_into is not None), B * H * W, C, ws.data_ptr(),
+                                     ext_partial.data_ptr() if ext_partial is not None else None,
+                                     ext_partial.shape[0] if ext_partial is not None else 0,
                                      _stream()), "jspsr_bn_backward")
     if grads_into is not None:
         return dx, dres, None, None

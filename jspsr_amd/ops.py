@@ -560,6 +560,7 @@ _aux_streams = {}
 _marks = {}          # home stream -> events marking recent weight-gradient forks (run-ahead throttle)
 RUN_AHEAD = int(os.environ.get("JSPSR_RUN_AHEAD", "16"))
 wgrad_async = os.environ.get("JSPSR_WGRAD_ASYNC", "1") != "0"
+bn_reduce_fused = os.environ.get("JSPSR_BN_REDUCE_FUSE", "1") != "0"      # bn1's backward reduce in conv2's data-gradient epilogue
 
 
 def aux_streams():
@@ -926,9 +927,17 @@ class _ResUnit(torch.autograd.Function):
             dW2 = _wgrad_async(p2, dz2, z1, O, O, 3, 3, 1, 1, x_affine=aff1, x_relu=True)
         else:
             dW2 = _wgrad_async(p2, dz2, y1, O, O, 3, 3, 1, 1)
-        dy1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), z1.shape[1:3], 1, 1)
+        # bn1's backward reduce (sum dz, sum dz xhat) rides in the epilogue of the data gradient that produces dy1, where the
+        # launch is the patch kernel (the 64-channel bf16 layers on K2r keep the separate pass)
+        Bz, Hz, Wz, _ = z1.shape
+        part1 = None
+        if bn_reduce_fused and tr1 and K.dgrad_reduce_ok(cdt, Bz, Hz, Wz, O, O, 3, 3, 1, 1) and z1.is_contiguous():
+            par1 = K.bn_reduce_params(g1, b1, m1, i1)
+            dy1, part1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), z1.shape[1:3], 1, 1, red=(z1, par1))
+        else:
+            dy1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), z1.shape[1:3], 1, 1)
         del dz2
-        dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1, grads_into=sink1)
+        dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1, grads_into=sink1, ext_partial=part1)
         if sink1 is not None:
             _bn_ready(pg1, pb1)
         del dy1

@@ -532,3 +532,60 @@ def test_input_affine_is_refused_where_no_kernel_applies_it():
     assert not K.fused_input_ok(torch.float32, 1, 8, 8, 16, 16, 3, 3, 1, 1)
     with pytest.raises(JspsrHipError, match="in_affine"):
         K.conv2d_forward(x, K.pack_weight(torch.randn(16, 16, 3, 3, device="cuda"), 0, 16, torch.float32), None, 1, 1, in_affine=aff)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [
+    (2, 40, 56, 128),        # 8x16 tiles (< 1024 tiles of 16x16), ragged in both directions
+    (1, 64, 64, 256),
+    (2, 256, 256, 128),      # the 16x16-pixel x 64-channel tiles (>= 1024), two N tiles per pixel tile
+    (1, 100, 36, 64),        # 64 channels below the K2r threshold (bf16) / fp32: patch kernel
+])
+def test_bn_backward_reduce_fused_into_the_data_gradient_epilogue(dtype, B, H, W, C):
+    """the reduce pass of bn1's backward (sum dz, sum dz xhat; conv -> BN -> ReLU -> conv of BasicBlock,
+    basics.py:111-117) taken in the epilogue of conv2's data gradient (jspsr_conv2d_dgrad: red_*) instead of by a pass of its
+    own: same dz1, dgamma, dbeta as the separate pass up to the order of the fp32 sums."""
+    from jspsr_amd import kernels as K
+    assert K.dgrad_reduce_ok(dtype, B, H, W, C, C, 3, 3, 1, 1)
+    g_ = torch.Generator().manual_seed(C + H)
+    dz2 = torch.randn(B, H, W, C, generator=g_).to(dtype).cuda()
+    z1 = (1.5 * torch.randn(B, H, W, C, generator=g_) + 0.3).to(dtype).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g_) / (3 * C ** 0.5)).cuda()
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g_)).cuda(), (0.2 * torch.randn(C, generator=g_)).cuda()
+    zf = z1.float()
+    mean = zf.mean((0, 1, 2)).contiguous()
+    invstd = (zf.var((0, 1, 2), unbiased=False) + 1e-5).rsqrt().contiguous()
+    wpt = K.pack_weight(w, 1, C, dtype)
+    names = ("bn_bwd_reduce", "bn_reduce_params")
+    from jspsr_amd import _lib
+    cnt = lambda: {n: _lib.load().jspsr_launch_count(n.encode()) for n in names}
+    # separate passes
+    dy_a = K.conv2d_dgrad(dz2, wpt, (H, W), 1, 1)
+    c0 = cnt()
+    dz_a, _, dg_a, db_a = K.bn_backward(dy_a, None, z1, gamma, mean, invstd, True, 2, 1.0, beta=beta)
+    assert cnt()["bn_bwd_reduce"] == c0["bn_bwd_reduce"] + 1
+    # fused
+    par = K.bn_reduce_params(gamma, beta, mean, invstd)
+    dy_b, part = K.conv2d_dgrad(dz2, wpt, (H, W), 1, 1, red=(z1, par))
+    c1 = cnt()
+    dz_b, _, dg_b, db_b = K.bn_backward(dy_b, None, z1, gamma, mean, invstd, True, 2, 1.0, beta=beta, ext_partial=part)
+    assert cnt()["bn_bwd_reduce"] == c1["bn_bwd_reduce"]            # no reduce pass this time
+    assert torch.equal(dy_a, dy_b)                                    # the data gradient itself is untouched
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert rel(dg_b, dg_a) < 2e-5 and rel(db_b, db_a) < 2e-5, (rel(dg_b, dg_a), rel(db_b, db_a))
+    # fp64 reference of the two sums from the stored dy and z1
+    dyd, zd = dy_a.double().cpu(), z1.double().cpu()
+    xhat = (zd - mean.double().cpu()) * invstd.double().cpu()
+    dzr = torch.where(gamma.double().cpu() * xhat + beta.double().cpu() > 0, dyd, torch.zeros((), dtype=torch.float64))
+    assert rel(db_b.cpu(), dzr.sum((0, 1, 2))) < 2e-5 and rel(dg_b.cpu(), (dzr * xhat).sum((0, 1, 2))) < 2e-5
+    if dtype == torch.float32:
+        assert rel(dz_b, dz_a) < 1e-5
+    else:
+        assert rel(dz_b, dz_a) < 2e-3 and (dz_b != dz_a).float().mean().item() < 0.02      # one-ulp flips where the coefficients moved
+
+
+def test_fused_reduce_is_refused_where_k2r_runs():
+    from jspsr_amd import kernels as K
+    assert not K.dgrad_reduce_ok(torch.bfloat16, 8, 512, 512, 64, 64, 3, 3, 1, 1)     # K2r's layers keep the separate pass
+    assert K.dgrad_reduce_ok(torch.float32, 8, 512, 512, 64, 64, 3, 3, 1, 1)
+    assert not K.dgrad_reduce_ok(torch.bfloat16, 8, 512, 512, 128, 128, 3, 3, 2, 1)   # stride 1 only
