@@ -560,6 +560,7 @@ _aux_streams = {}
 _marks = {}          # home stream -> events marking recent weight-gradient forks (run-ahead throttle)
 RUN_AHEAD = int(os.environ.get("JSPSR_RUN_AHEAD", "16"))
 wgrad_async = os.environ.get("JSPSR_WGRAD_ASYNC", "1") != "0"
+wgrad_one_stream = os.environ.get("JSPSR_WGRAD_ONE_STREAM", "0") != "0"   # lab: ONE weight-gradient stream for all home streams
 bn_reduce_fused = os.environ.get("JSPSR_BN_REDUCE_FUSE", "1") != "0"      # bn1's backward reduce in conv2's data-gradient epilogue
 
 
@@ -572,9 +573,10 @@ def _wgrad_async(param, G, X, R, C, KH, KW, stride, pad, **kw):
     if not wgrad_async:
         return _wgrad_into(param, G, X, R, C, KH, KW, stride, pad, **kw)
     cur = torch.cuda.current_stream()
-    aux = _aux_streams.get(cur.cuda_stream)
+    key = 0 if wgrad_one_stream else cur.cuda_stream
+    aux = _aux_streams.get(key)
     if aux is None:
-        aux = _aux_streams[cur.cuda_stream] = torch.cuda.Stream(device=G.device)
+        aux = _aux_streams[key] = torch.cuda.Stream(device=G.device)
     aux.wait_stream(cur)                     # G and X are complete on the home stream
     with torch.cuda.stream(aux):
         dW = _wgrad_into(param, G, X, R, C, KH, KW, stride, pad, **kw)
