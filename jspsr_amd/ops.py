@@ -560,6 +560,7 @@ _aux_streams = {}
 _marks = {}          # home stream -> events marking recent weight-gradient forks (run-ahead throttle)
 RUN_AHEAD = int(os.environ.get("JSPSR_RUN_AHEAD", "16"))
 wgrad_async = os.environ.get("JSPSR_WGRAD_ASYNC", "1") != "0"
+wgrad_after_dgrad = os.environ.get("JSPSR_WGRAD_AFTER_DGRAD", "0") != "0"   # lab: weight gradients forked behind their layer's data gradient
 wgrad_one_stream = os.environ.get("JSPSR_WGRAD_ONE_STREAM", "0") != "0"   # lab: ONE weight-gradient stream for all home streams
 bn_reduce_fused = os.environ.get("JSPSR_BN_REDUCE_FUSE", "1") != "0"      # bn1's backward reduce in conv2's data-gradient epilogue
 
@@ -925,10 +926,16 @@ class _ResUnit(torch.autograd.Function):
         if dres is None:
             dres = dout
         p1, p2, pd = ctx.wparams
-        if aff1 is not None:      # conv2's input was never materialised: its weight gradient re-forms relu(bn1(z1)) while staging
-            dW2 = _wgrad_async(p2, dz2, z1, O, O, 3, 3, 1, 1, x_affine=aff1, x_relu=True)
-        else:
-            dW2 = _wgrad_async(p2, dz2, y1, O, O, 3, 3, 1, 1)
+
+        def wgrad2():
+            if aff1 is not None:      # conv2's input was never materialised: its weight gradient re-forms relu(bn1(z1)) while staging
+                return _wgrad_async(p2, dz2, z1, O, O, 3, 3, 1, 1, x_affine=aff1, x_relu=True)
+            return _wgrad_async(p2, dz2, y1, O, O, 3, 3, 1, 1)
+
+        # lab (JSPSR_WGRAD_AFTER_DGRAD=1): fork each weight gradient BEHIND the data gradient of the same layer, so that it starts
+        # beside the HBM-bound BatchNorm passes that follow instead of beside an MFMA-bound data gradient
+        if not wgrad_after_dgrad:
+            dW2 = wgrad2()
         # bn1's backward reduce (sum dz, sum dz xhat) rides in the epilogue of the data gradient that produces dy1, where the
         # launch is the patch kernel (the 64-channel bf16 layers on K2r keep the separate pass)
         Bz, Hz, Wz, _ = z1.shape
@@ -938,12 +945,14 @@ class _ResUnit(torch.autograd.Function):
             dy1, part1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), z1.shape[1:3], 1, 1, red=(z1, par1))
         else:
             dy1 = K.conv2d_dgrad(dz2, _packed(p2, w2, 1, O, cdt), z1.shape[1:3], 1, 1)
+        if wgrad_after_dgrad:
+            dW2 = wgrad2()
         del dz2
         dz1, _, dg1, db1 = K.bn_backward(dy1, None, z1, g1, m1, i1, tr1, 2, 1.0, beta=b1, grads_into=sink1, ext_partial=part1)
         if sink1 is not None:
             _bn_ready(pg1, pb1)
         del dy1
-        dW1 = _wgrad_async(p1, dz1, x, O, Cin, 3, 3, stride, 1)
+        dW1 = None if wgrad_after_dgrad else _wgrad_async(p1, dz1, x, O, Cin, 3, 3, stride, 1)
         dWd = dgd = dbd = None
         side = dres                      # what reaches x along the shortcut
         # gradient of x parked by its other consumer (SliceBuffer.join(defer=...)): rides along as an addend too
@@ -990,6 +999,8 @@ class _ResUnit(torch.autograd.Function):
             ctx.grad_extra[0].deposit_events.append(torch.cuda.current_stream().record_event())
         elif need_x:
             dx = K.conv2d_dgrad(dz1, _packed(p1, w1, 1, O, cdt), (H, W), stride, 1, addend=K.nhwc(side))
+        if wgrad_after_dgrad:
+            dW1 = _wgrad_async(p1, dz1, x, O, Cin, 3, 3, stride, 1)
         return (dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None, None, None, None, None)
 
 
