@@ -78,34 +78,8 @@ constexpr int R_RUN = 4;                                  // tiles per claim of 
 constexpr int R_ROT = 14;                                 // see conv_patch_kernel: row r of the tile is rotated by 14 r
 constexpr int NK = 72, LA = K2R_LA;                       // MFMA steps per tile; look-ahead
 
-typedef __attribute__((address_space(3))) void* lptr_t;
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
 struct Tile { int bimg, tyi, txi; };
 struct PatchSrc { i32x4 desc; int oy0, ox0; bool interior; };
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // one v_cvt_pk_bf16_f32
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-// max(x, 0) on the bit pattern: one v_max_i32 (a negative float is a negative integer; -0 and negative NaNs become +0)
-__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
-// 8 bf16 + 8 bf16 (fp32 add, one rounding), optional ReLU
-__device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b, bool relu) {
-  u32x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
-    float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
-    if (relu) { lo = relu_bits(lo); hi = relu_bits(hi); }
-    r[i] = pack_bf16(lo, hi);
-  }
-  return r;
-}
 
 template <int SIGN, int MODE>      // MODE 0: plain, 1: + BatchNorm statistics, 2: + per-channel scale / bias
 __global__ __launch_bounds__(R_NTH) void conv64_resident_kernel(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt,

@@ -63,10 +63,42 @@ struct ConvGeom {
   float* red_out;
 };
 
+// ---- shared by the register-resident kernels (conv64.hip, conv128.hip) ------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // one v_cvt_pk_bf16_f32
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// max(x, 0) on the bit pattern: one v_max_i32 (a negative float is a negative integer; -0 and negative NaNs become +0)
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// 8 bf16 + 8 bf16 (fp32 add, one rounding), optional ReLU
+__device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b, bool relu) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = __uint_as_float(a[i] << 16) + __uint_as_float(b[i] << 16);
+    float hi = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(b[i] & 0xffff0000u);
+    if (relu) { lo = relu_bits(lo); hi = relu_bits(hi); }
+    r[i] = pack_bf16(lo, hi);
+  }
+  return r;
+}
+
+
 // K2r (conv64.hip): 3x3 64->64 unit-stride bf16 conv / data gradient, weights resident in registers
 bool conv64_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const float* bias, const void* out);
 int launch_conv64_resident(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g,
                            hipStream_t s);
+
+// K2q (conv128.hip): 3x3 128->128 unit-stride bf16 conv / data gradient, the weight matrix resident in one CU's registers
+bool conv128_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const float* bias, const void* out);
+int launch_conv128_resident(const void* in, const void* wgt, void* out, float* stats, const ConvGeom& g, hipStream_t s);
 
 }  // namespace jspsr
 
