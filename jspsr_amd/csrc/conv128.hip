@@ -67,10 +67,10 @@ constexpr int Q_NK = 144, Q_LAH = K2Q_LA;                   // fragment reads pe
 __device__ __forceinline__ int inbox_off(int wave) { return wave == 0 ? Q_PATCHB : Q_BUF1 + Q_PATCHB + (wave - 1) * Q_XCHB; }
 
 // v[c] += v[c] of the lane SH places further round the 16-lane DPP row (row_ror): after 8, 4, 2, 1 every lane holds the row's sum
-template <int SH>
-__device__ __forceinline__ void row_sum(float (&v)[16]) {
+template <int SH, int N>
+__device__ __forceinline__ void row_sum(float (&v)[N]) {
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
+  for (int c = 0; c < N; ++c)
     v[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[c]), 0x120 + SH, 0xf, 0xf, false));
 }
 
@@ -156,13 +156,6 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
   // ---- patch DMA: lane (n, q) of piece i fills chunk POSITION n of patch pixel P = 4 i + q with chunk n ^ 2 (P & 7) ----------
   const int pix_bytes = g.in_cstride * 2;
   constexpr int back = SIGN < 0 ? 2 : 0;     // reversed walk: the patch starts two pixels earlier
-  unsigned dsrc[Q_NP];
-#pragma unroll
-  for (int i = 0; i < Q_NP; ++i) {
-    const int P = 4 * (wave + 4 * i) + q;
-    const int py = P / Q_PW, px = P - py * Q_PW;
-    dsrc[i] = (wave + 4 * i < Q_PIECES) ? (unsigned)((py * g.IW + px) * pix_bytes + ((n ^ (2 * (P & 7))) << 4)) : 0xFFFFFFF0u;
-  }
   auto patch_src = [&](QTile tc, bool more) {
     QSrc p;
     p.oy0 = tc.tyi * Q_TH + g.iy_add - back;
@@ -177,13 +170,18 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
   // offset that fails the descriptor's range check: `buffer_load ... lds` then writes ZEROS for it -- the conv's zero padding.
   // Issued from inline asm without a memory clobber (the bytes land in the OTHER patch buffer, read after the next
   // barrier); M0 is written in the statement that uses it and by nothing else in this file (csrc/check_m0.sh).
+  // (the source offset of a lane is recomputed per piece -- a handful of VALU operations in the shadow of the MFMAs -- rather
+  // than kept in twelve registers; the swizzle term is the same for all pieces of a lane: 16 i = 0 (mod 8))
   const int p0lane = 4 * wave + q;
+  const unsigned swz16 = (unsigned)((n ^ (2 * (p0lane & 7))) << 4);
   auto issue_piece = [&](const QSrc& p, unsigned bufoff, int i) __attribute__((always_inline)) {
     const bool have = wave + 4 * i < Q_PIECES;                  // wave-uniform; false only for the 12th piece of waves 1-3
-    const int P = p0lane + 16 * i;
+    int p0 = p0lane;
+    asm volatile("" : "+v"(p0));                               // opaque: the compiler must not hoist twelve sets of tile-invariant coordinates into registers
+    const int P = p0 + 16 * i;
     const int py = (int)(__umul24(P, 3641) >> 16), px = P - (int)__umul24(py, Q_PW);        // P / 18 for P < 400
     const bool in_img = (unsigned)(p.oy0 + py) < (unsigned)g.IH && (unsigned)(p.ox0 + px) < (unsigned)g.IW;
-    const unsigned src = in_img ? dsrc[i] : 0xFFFFFFF0u;
+    const unsigned src = in_img ? (unsigned)((py * g.IW + px) * pix_bytes) + swz16 : 0xFFFFFFF0u;
     const unsigned dst = lds0 + (have ? bufoff + (unsigned)(wave + 4 * i) * 1024u : (unsigned)Q_OFF_DUMP);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src), "s"(p.desc));
   };
@@ -264,7 +262,7 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
       aoff[i] = inside[i] ? pix * (unsigned)(g.add_cstride * 2) + q * 16u : 0xFFFFFFF0u;
     }
     u32x4 av[4][2];
-    if (g.addend) {
+    if (!STATS && g.addend) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -272,37 +270,51 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     }
     if constexpr (STATS) {
       if (stats) {
-        // per-channel sum and sum of squares over this wave's 4 x 16 pixels: rows in-lane, the 16 columns across the DPP row
-        float s1[16], s2[16];
+        // per-channel sum and sum of squares over this wave's 4 x 16 pixels: rows in-lane, the 16 columns across the DPP row;
+        // eight channels (one 16-byte run) at a time
+        const bool whole = tc.tyi * Q_TH + Q_TH <= g.MH && tc.txi * Q_TW + Q_TW <= g.MW;      // wave-uniform
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+        for (int h = 0; h < 2; ++h) {
+          float s1[8], s2[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float m = inside[i] ? 1.f : 0.f;
+          for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+          if (whole) {
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float a0 = acc[4 * KH + i][cb][j] * m;
-              s1[cb * 4 + j] += a0;
-              s2[cb * 4 + j] = __builtin_fmaf(a0, a0, s2[cb * 4 + j]);
+              for (int c = 0; c < 8; ++c) {
+                const float a0 = acc[4 * KH + i][2 * h + (c >> 2)][c & 3];
+                s1[c] += a0;
+                s2[c] = __builtin_fmaf(a0, a0, s2[c]);
+              }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float m = inside[i] ? 1.f : 0.f;
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                const float a0 = acc[4 * KH + i][2 * h + (c >> 2)][c & 3] * m;
+                s1[c] += a0;
+                s2[c] = __builtin_fmaf(a0, a0, s2[c]);
+              }
             }
-        }
-        row_sum<8>(s1); row_sum<8>(s2);
-        row_sum<4>(s1); row_sum<4>(s2);
-        row_sum<2>(s1); row_sum<2>(s2);
-        row_sum<1>(s1); row_sum<1>(s2);
-        if (n == 0) {
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb) {
-            const int c0 = 64 * cg + 32 * (cb >> 1) + 8 * q + 4 * (cb & 1);
-            *reinterpret_cast<f32x4*>(red + (KH * 2 + 0) * 128 + c0) = f32x4{s1[cb * 4], s1[cb * 4 + 1], s1[cb * 4 + 2], s1[cb * 4 + 3]};
-            *reinterpret_cast<f32x4*>(red + (KH * 2 + 1) * 128 + c0) = f32x4{s2[cb * 4], s2[cb * 4 + 1], s2[cb * 4 + 2], s2[cb * 4 + 3]};
+          }
+          row_sum<8>(s1); row_sum<8>(s2);
+          row_sum<4>(s1); row_sum<4>(s2);
+          row_sum<2>(s1); row_sum<2>(s2);
+          row_sum<1>(s1); row_sum<1>(s2);
+          if (n == 0) {
+            float* r1 = red + (KH * 2 + 0) * 128 + 64 * cg + 32 * h + 8 * q;
+            float* r2 = red + (KH * 2 + 1) * 128 + 64 * cg + 32 * h + 8 * q;
+            *reinterpret_cast<f32x4*>(r1) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<f32x4*>(r1 + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
+            *reinterpret_cast<f32x4*>(r2) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+            *reinterpret_cast<f32x4*>(r2 + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
           }
         }
       }
     }
-    if (relu_first) {      // wave-uniform
+    if (!STATS && relu_first) {      // wave-uniform
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -316,7 +328,7 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
       for (int h = 0; h < 2; ++h) {
         const f32x4 lo = acc[4 * KH + i][2 * h], hi = acc[4 * KH + i][2 * h + 1];
         u32x4 o = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
-        if (g.addend) o = add_bf16x8(o, av[i][h], relu_last);
+        if (!STATS && g.addend) o = add_bf16x8(o, av[i][h], relu_last);
         __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[i], h * 64, 0);
       }
   };
@@ -412,6 +424,7 @@ bool conv128_resident_ok(const ConvGeom& g, const void* in, const void* wgt, con
   if (g.Cin != 128 || g.Cout != 128 || g.nty != 3 || g.ntx != 3 || g.KH != 3 || g.KW != 3) return false;
   if (g.iy_mul != 1 || g.ix_mul != 1 || g.oy_mul != 1 || g.ox_mul != 1 || g.oy_add != 0 || g.ox_add != 0) return false;
   if (g.ky0 != 0 || g.kx0 != 0 || g.kstep != 1 || g.in_affine || g.red_out || bias || g.scale) return false;
+  // (the statistics form is the plain training forward: jspsr_conv2d_forward refuses statistics with bias / ReLU / addend)
   if (g.in_cstride % 8 || g.in_coff % 8 || g.out_cstride % 8 || g.out_coff % 8) return false;
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;
