@@ -33,6 +33,8 @@
 // Out-of-image patch pixels fail the buffer descriptor's range check and land as zeros (the conv's zero padding).
 #include "conv_igemm.h"
 
+#include <atomic>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -52,6 +54,9 @@ constexpr int Q_BUF1 = 65536;                               // the second patch 
 constexpr int Q_XCHB = 16384;                               // inbox of one wave: 4 rows x 4 channel blocks x 1 KiB
 constexpr int Q_OFF_RED = Q_PATCHB + Q_XCHB;                // [2 kh][2][128] floats (statistics fold), inside the first 64 KiB
 static_assert(Q_OFF_RED + 2048 <= Q_BUF1, "the first 64 KiB hold patch 0, inbox 0 and the fold");
+constexpr int Q_OFF_RUN = Q_OFF_RED + 2048;                // two published run starts of the dynamic tile queue
+static_assert(Q_OFF_RUN + 16 <= Q_BUF1, "run starts inside the first 64 KiB");
+constexpr int Q_RUN = 4;                                    // tiles per draw (x-neighbours: their halo columns stay in this XCD's L2)
 constexpr int Q_OFF_DUMP = Q_BUF1 + Q_PATCHB + 3 * Q_XCHB;  // 1 KiB nobody reads: where the piece a wave does not have lands
 constexpr int Q_LDS = Q_OFF_DUMP + 1024;                    // 161 792
 static_assert(Q_LDS <= 163840, "LDS of one CU");
@@ -117,7 +122,7 @@ struct QSrc { i32x4 desc; int oy0, ox0; };
 
 template <int SIGN, int MODE, int KH>      // MODE 0: plain (+ addend / ReLU), 1: + BatchNorm statistics
 __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt, __bf16* __restrict__ out,
-                                             float* __restrict__ stats, const ConvGeom& g, int ntiles, char* smem) {
+                                             float* __restrict__ stats, const ConvGeom& g, int ntiles, unsigned* __restrict__ ticket, char* smem) {
   constexpr bool STATS = MODE == 1;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int cg = wave & 1;                                  // (KH = wave >> 1)
@@ -166,6 +171,8 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     p.desc = i32x4{(int)(unsigned)b64, (int)((unsigned)(b64 >> 32) & 0xffffu), more ? (int)0xFFFFFF00u : 0, 0x00020000};
     return p;
   };
+  // (s_nop 4 between the M0 write and the DMA: 1 wait state for M0, 5 for a descriptor SGPR that a VALU instruction -- a
+  // v_readfirstlane of tile coordinates that came through LDS, dynamic walk -- may have written just before the statement)
   // One piece, branch-free (it sits between the MFMAs of the tap loop).  A lane whose pixel lies outside the image gets an
   // offset that fails the descriptor's range check: `buffer_load ... lds` then writes ZEROS for it -- the conv's zero padding.
   // Issued from inline asm without a memory clobber (the bytes land in the OTHER patch buffer, read after the next
@@ -183,7 +190,7 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     const bool in_img = (unsigned)(p.oy0 + py) < (unsigned)g.IH && (unsigned)(p.ox0 + px) < (unsigned)g.IW;
     const unsigned src = in_img ? (unsigned)((py * g.IW + px) * pix_bytes) + swz16 : 0xFFFFFFF0u;
     const unsigned dst = lds0 + (have ? bufoff + (unsigned)(wave + 4 * i) * 1024u : (unsigned)Q_OFF_DUMP);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src), "s"(p.desc));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src), "s"(p.desc));
   };
 
   // ---- patch-fragment plan: lane (n, q) reads chunk 8 KH + 4 s + q of patch pixel 18 R + tx + n ---------------------------------
@@ -194,9 +201,20 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     for (int tx = 0; tx < 3; ++tx)
       abase[b][tx] = (unsigned)((Q_PW * b + tx + n) * Q_PIXB + (((8 * KH + q) ^ (2 * ((2 * b + tx + n) & 7))) << 4));
 
+  // The addend of a tile (the gradient arriving along the shortcut) is read in the epilogue, where nothing hides an HBM miss:
+  // one more DMA piece early in the tap loop touches this wave's 64 lines of it (pixel (4 KH + q, n), 128 B each) and lands
+  // in the dump -- the epilogue's loads then hit L2.  No addend: an empty descriptor.
+  auto prefetch_addend = [&](QTile tc) __attribute__((always_inline)) {
+    const int y = tc.tyi * Q_TH + 4 * KH + q, x = tc.txi * Q_TW + n;
+    const unsigned off = (y < g.MH && x < g.MW) ? (unsigned)(y * g.OW + x) * (unsigned)(g.add_cstride * 2) : 0xFFFFFFF0u;
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(g.addend) + ((long long)tc.bimg * g.OH * g.OW * g.add_cstride + 64 * cg) * 2;
+    const i32x4 d = {(int)(unsigned)b64, (int)((unsigned)(b64 >> 32) & 0xffffu), g.addend ? (int)0xFFFFFF00u : 0, 0x00020000};
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds0 + (unsigned)Q_OFF_DUMP), "v"(off), "s"(d));
+  };
+
   // ---- the tap loop: 144 fragment reads x 4 MFMAs, weights from registers -----------------------------------------------------
   f32x4 acc[8][4];
-  auto mfma_tile = [&](const QSrc& nxt, unsigned nbufoff) __attribute__((always_inline)) {
+  auto mfma_tile = [&](const QSrc& nxt, unsigned nbufoff, QTile tc) __attribute__((always_inline)) {
     i32x4 a[Q_LAH];
     static_for<0, Q_NK + Q_LAH>([&](auto K) __attribute__((always_inline)) {
       constexpr int k = decltype(K)::value;
@@ -212,6 +230,7 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
         constexpr int R = r + ty;
         a[k % Q_LAH] = *reinterpret_cast<const i32x4*>(smem + ((abase[R & 3][tx] ^ (unsigned)(s * 64)) + (unsigned)((R >> 2) * Q_ROWS4)));
         if constexpr (K2Q_DMA_MODE == 1 && k % 12 == 5) issue_piece(nxt, nbufoff, k / 12);
+        if constexpr (!STATS && k == 1) prefetch_addend(tc);
       }
     });
     // the accumulators are read by ordinary instructions next: the compiler does not know an MFMA wrote them
@@ -338,8 +357,26 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     stats[((size_t)((tc.bimg * tty + tc.tyi) * ttx + tc.txi) * 2 + which) * 128 + col] = red[which * 128 + col] + red[(2 + which) * 128 + col];
   };
 
+  // Tile walk.  Static (ticket == nullptr): tile v, v + G, v + 2G ... -- fine alone on the chip.  Dynamic: the workgroups draw
+  // runs of Q_RUN x-neighbouring tiles from one global ticket.  A workgroup of this kernel needs a WHOLE CU (all of its LDS,
+  // every register of its four SIMDs): beside the weight-gradient kernels of the other streams some CUs come free late, and
+  // with the static walk the launch would end that much late -- here such a workgroup simply draws fewer runs.  A draw is
+  // issued by thread 0 when the walk ENTERS a run (for the run after the next), published in LDS at the end of that tile
+  // (the wait-count there has covered it) and read behind a barrier at least one tile later.
+  const bool dyn = ticket != nullptr;
+  int* const s_run = reinterpret_cast<int*>(smem + Q_OFF_RUN);
+  if (dyn) {
+    if (tid == 0) {
+      s_run[0] = (int)__hip_atomic_fetch_add(ticket, (unsigned)Q_RUN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_run[1] = (int)__hip_atomic_fetch_add(ticket, (unsigned)Q_RUN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
   auto tile_of = [&](int t_) { return QTile{(t_ / ttx) / tty, (t_ / ttx) % tty, t_ % ttx}; };
-  int t = v, it = 0;
+  int t = dyn ? s_run[0] : v, it = 0;
+  int krun = 0, nrun = 0;                 // dynamic: position of tile t in its run, number of that run
+  unsigned pend = 0;                      // thread 0: a drawn run start not yet published
+  int pend_slot = -1;
   QTile tcur = tile_of(t < ntiles ? t : 0), tprev = tcur;
   unsigned bufoff = 0;
   if (t < ntiles) {
@@ -359,15 +396,38 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (STATS && stats && it > 0) flush_stats(tprev);
-    const int tn = t + G;
+    int tn, kn = 0, nn = nrun;
+    QTile tnext;
+    if (!dyn) {
+      tn = t + G;
+      tnext = advance(tcur);
+    } else if (krun + 1 < Q_RUN && t + 1 < ntiles) {
+      tn = t + 1;
+      kn = krun + 1;
+      tnext = tcur;
+      if (++tnext.txi == ttx) { tnext.txi = 0; if (++tnext.tyi == tty) { tnext.tyi = 0; ++tnext.bimg; } }
+    } else {
+      nn = nrun + 1;
+      tn = s_run[nn & 1];                 // published at least one barrier ago
+      tnext = tile_of(tn < ntiles ? tn : 0);
+    }
+    if (dyn && tid == 0 && krun == 0) {   // entering run nrun: draw run nrun + 2 into the slot run nrun no longer needs
+      // from inline asm, in place in `pend`: as a builtin the compiler waits for the returned value (vmcnt(0): the stores of the
+      // tile before and the round trip) at the end of this block, where the loop-carried variable is merged; the value is
+      // first read at the end of the tile, behind the wait-count that covers it
+      // (s_nop 4: the compiler may have just produced the pointer's SGPRs with a VALU instruction -- v_readlane from its
+      // SGPR-spill register -- and a vector-memory instruction must not read such an SGPR within 5 wait states; the compiler
+      // does not look into an asm statement for that hazard)
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "+v"(pend) : "v"(0u), "v"((unsigned)Q_RUN), "s"(ticket));
+      pend_slot = nrun & 1;
+    }
     const bool more = tn < ntiles;
-    const QTile tnext = advance(tcur);
     const QSrc nxt = patch_src(tnext, more);
     if (K2Q_DMA_MODE == 0) {
 #pragma unroll
       for (int i = 0; i < Q_NP; ++i) issue_piece(nxt, bufoff ^ Q_BUF1, i);
     }
-    mfma_tile(nxt, bufoff ^ Q_BUF1);
+    mfma_tile(nxt, bufoff ^ Q_BUF1, tcur);
     hand_over();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -383,9 +443,20 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     // this wave's pieces of the next patch have landed once all but its 8 youngest vector-memory operations (the stores of
     // the epilogue; the pieces and the addend loads are older) are done
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (dyn && tid == 0 && pend_slot >= 0) { s_run[pend_slot] = (int)pend; pend_slot = -1; }
     tprev = tcur;
     tcur = tnext;
-    t = tn;
+    t = tn; krun = kn; nrun = nn;
+  }
+  if (dyn && tid == 0) {
+    // last workgroup out re-arms the ticket for the launch that gets this slot next (1024 launches from now); every draw of
+    // this workgroup has returned before it signs off
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const unsigned old = __hip_atomic_fetch_add(ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)G - 1u) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (STATS && stats && it > 0) {
     __syncthreads();
@@ -396,11 +467,24 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
 template <int SIGN, int MODE>
 __global__ __launch_bounds__(Q_NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv128_resident_kernel(
     const __bf16* __restrict__ in, const __bf16* __restrict__ wgt, __bf16* __restrict__ out, float* __restrict__ stats, ConvGeom g,
-    int ntiles) {
+    int ntiles, unsigned* __restrict__ ticket) {
   extern __shared__ __attribute__((aligned(128))) char smem[];
   // the K-half of a wave decides which accumulators it keeps: compile-time per branch (wave-uniform, scalar branch)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) conv128_body<SIGN, MODE, 0>(in, wgt, out, stats, g, ntiles, smem);
-  else conv128_body<SIGN, MODE, 1>(in, wgt, out, stats, g, ntiles, smem);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) conv128_body<SIGN, MODE, 0>(in, wgt, out, stats, g, ntiles, ticket, smem);
+  else conv128_body<SIGN, MODE, 1>(in, wgt, out, stats, g, ntiles, ticket, smem);
+}
+
+// Tickets of the dynamic tile queue: (next tile, workgroups done) pairs, handed out round-robin per launch; the last
+// workgroup of a launch zeroes its pair again, and a slot comes round after 1024 launches.
+__device__ unsigned k2q_ring[2 * 1024];
+
+unsigned* next_ticket() {
+  static unsigned* base = [] {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(k2q_ring)) == hipSuccess ? static_cast<unsigned*>(p) : nullptr;
+  }();
+  static std::atomic<unsigned> n{0};
+  return base ? base + 2 * (n.fetch_add(1, std::memory_order_relaxed) % 1024u) : nullptr;
 }
 
 template <int SIGN, int MODE>
@@ -410,8 +494,14 @@ void launch_k2q(const void* in, const void* wgt, void* out, float* stats, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv128_resident_kernel<SIGN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
     attr_set = true;
   }
+  // dynamic tile queue (opt-in: JSPSR_CONV_DYNQ128=1) once every workgroup has several runs to draw.  Measured on one box:
+  // alone on the chip the static walk is 5 % faster (8 x 512^2 forward 486 vs 510 us: tile coordinates that come through LDS
+  // are per-lane values to the compiler, and neighbouring tiles no longer share an XCD's L2); in the multi-stream step
+  // 63.6 / 64.3 / 64.4 ms static against 63.1 / 64.3 / 64.4 dynamic, three interleaved runs each -- no difference.
+  static const int dynq = [] { const char* e = getenv("JSPSR_CONV_DYNQ128"); return e ? atoi(e) : 0; }();
+  unsigned* ticket = (dynq && (long long)ntiles >= 4LL * Q_RUN * grid) ? next_ticket() : nullptr;
   hipLaunchKernelGGL((conv128_resident_kernel<SIGN, MODE>), dim3(grid), dim3(Q_NTH), Q_LDS, s, static_cast<const __bf16*>(in),
-                     static_cast<const __bf16*>(wgt), static_cast<__bf16*>(out), stats, g, ntiles);
+                     static_cast<const __bf16*>(wgt), static_cast<__bf16*>(out), stats, g, ntiles, ticket);
 }
 
 }  // namespace

@@ -192,6 +192,60 @@ def test_conv_resident_weights_path(B, H, W):
     assert _relerr(_nchw(dx.float()), xx.grad.bfloat16().double() + res.double()) < 6e-3
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 256, 512), (4, 250, 512), (1, 512, 520)])
+def test_conv_resident_128_path(B, H, W):
+    """3x3 128->128 bf16 convs on >= 2048 tiles of 8x16 pixels run K2q (conv128.hip: the whole weight matrix in one CU's
+    registers, one patch-fragment read per four MFMAs, swizzled LDS-DMA patches, the two K-halves of a channel group meeting
+    through LDS): training forward with the BatchNorm partial statistics on ragged rasters, plain forward with ReLU, channel
+    slices on both sides, and the data gradient (reversed tap walk) with an addend and with ReLU."""
+    K = _k()
+    from jspsr_amd import _lib
+    lib = _lib.load()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(B + H + W)
+    x = torch.randn(B, 128, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34.0).bfloat16().float()
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    wp = K.pack_weight(w.cuda(), 0, 128, dtype)
+    xd = _nhwc(x).to(dtype)
+    n0 = lib.jspsr_launch_count(b"conv128_resident")
+    y, st = K.conv2d_forward(xd, wp, None, 1, 1, stats=True)
+    assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 1
+    assert _relerr(_nchw(y.float()), ref) < 6e-3
+    edge = torch.zeros(H, W, dtype=torch.bool)
+    edge[0] = edge[-1] = True
+    edge[:, 0] = edge[:, -1] = True
+    assert _relerr(_nchw(y.float())[..., edge], ref[..., edge]) < 6e-3
+    tot = st.double().sum(0).cpu()
+    assert _relerr(tot[0], ref.sum((0, 2, 3))) < 1e-4 and _relerr(tot[1], (ref * ref).sum((0, 2, 3))) < 1e-5
+    # statistics rows are numbered by 8x16 tiles: each row holds exactly its own pixels
+    rows = st.double().cpu().reshape(B, (H + 7) // 8, (W + 15) // 16, 2, 128)
+    r8 = F.pad(ref, (0, -W % 16, 0, -H % 8)).reshape(B, 128, (H + 7) // 8, 8, (W + 15) // 16, 16).sum((3, 5)).permute(0, 2, 3, 1)
+    assert (rows[..., 0, :] - r8).abs().max() < 1e-3 * r8.abs().max()
+    q8 = F.pad(ref * ref, (0, -W % 16, 0, -H % 8)).reshape(B, 128, (H + 7) // 8, 8, (W + 15) // 16, 16).sum((3, 5)).permute(0, 2, 3, 1)
+    assert (rows[..., 1, :] - q8).abs().max() < 1e-3 * q8.abs().max()
+    # ReLU, reading a channel slice of a wider tensor and writing into a slice of a wider one
+    wide = torch.randn(B, H, W, 192, generator=g).bfloat16().cuda()
+    wide[..., 32:160] = xd
+    out = torch.full((B, H, W, 256), 7.0, dtype=dtype, device="cuda")
+    K.conv2d_forward(wide, wp, None, 1, 1, relu=True, out=out, out_coff=64, cin=128, in_coff=32)
+    assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 2
+    assert _relerr(_nchw(out[..., 64:192].float()), F.relu(ref)) < 6e-3
+    assert (out[..., :64] == 7.0).all() and (out[..., 192:] == 7.0).all()
+    del wide, out
+    # data gradient, plain and with an addend + ReLU
+    res = torch.randn(B, 128, H, W, generator=g).bfloat16().float()
+    go = torch.randn(B, 128, H, W, generator=g).bfloat16().float()
+    xx = torch.zeros(B, 128, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xx, w.double(), None, 1, 1).backward(go.double())
+    wpt = K.pack_weight(w.cuda(), 1, 128, dtype)
+    dx = K.conv2d_dgrad(_nhwc(go).to(dtype), wpt, (H, W), 1, 1)
+    assert _relerr(_nchw(dx.float()), xx.grad) < 6e-3
+    dx = K.conv2d_dgrad(_nhwc(go).to(dtype), wpt, (H, W), 1, 1, addend=_nhwc(res).to(dtype), relu=True)
+    assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 4
+    assert _relerr(_nchw(dx.float()), F.relu(xx.grad.bfloat16().double() + res.double())) < 6e-3
+
+
 def test_conv_resident_kernels_overlap_on_two_streams():
     """K2r is a persistent kernel (one workgroup per CU, most of the CU's LDS and registers) with no device-global state:
     launches of its three modes queued on two streams at once -- as the step's branch streams do -- must give the bits of
@@ -413,10 +467,11 @@ def test_conv_epilogue_statistics(dtype, B, H, W, Cin, Cout, k, stride, pad):
 
 
 @pytest.mark.parametrize("env", [{"JSPSR_CONV_TALL": "2"}, {"JSPSR_CONV_NOPATCH": "1"}, {"JSPSR_WGRAD_NOPATCH": "1"},
-                                 {"JSPSR_CONV_TALL": "0"}, {"JSPSR_CONV_RESIDENT": "0"}, {"JSPSR_CONV_DYNQ": "1"}])
+                                 {"JSPSR_CONV_TALL": "0"}, {"JSPSR_CONV_RESIDENT": "0"}, {"JSPSR_CONV_DYNQ": "1"},
+                                 {"JSPSR_CONV_RESIDENT128": "0"}, {"JSPSR_CONV_DYNQ128": "1"}])
 def test_opt_in_kernel_variants_in_a_child_process(env):
     """The library reads its lab switches once per process: the opt-in / fallback instantiations (8-wave 256x128 tile,
-    generic implicit-GEMM kernel only, generic weight-gradient kernel only, no 16x16 tile, no register-resident 64-channel kernel, K2r's dynamic tile queue) are exercised in a child
+    generic implicit-GEMM kernel only, generic weight-gradient kernel only, no 16x16 tile, no register-resident 64-channel kernel, K2r's dynamic tile queue, no register-resident 128-channel kernel, K2q's dynamic tile queue) are exercised in a child
     process against the same fp64 reference, so that they stay correct while they are not the default."""
     import subprocess
     import sys
@@ -424,9 +479,11 @@ def test_opt_in_kernel_variants_in_a_child_process(env):
 import torch, torch.nn.functional as F
 from jspsr_amd import kernels as K
 g = torch.Generator().manual_seed(0)
-for (B, H, W, Ci, Co) in [(2, 256, 256, 64, 128), (4, 256, 256, 64, 64), (8, 512, 512, 64, 64)]:   # (the last: the dynamic tile queue's size)
-    if B == 8 and not __import__("os").environ.get("JSPSR_CONV_DYNQ"):
+for (B, H, W, Ci, Co) in [(2, 256, 256, 64, 128), (4, 256, 256, 64, 64), (8, 512, 512, 64, 64), (2, 256, 512, 128, 128), (4, 256, 512, 128, 128)]:
+    if B == 8 and not __import__("os").environ.get("JSPSR_CONV_DYNQ"):      # the dynamic tile queue's size
         continue
+    if Ci == 128 and not (B == 2 and __import__("os").environ.get("JSPSR_CONV_RESIDENT128") or B == 4 and __import__("os").environ.get("JSPSR_CONV_DYNQ128")):
+        continue      # K2q's size on the patch kernel; K2q's dynamic tile queue at the 4096 tiles it starts at
     x = torch.randn(B, Ci, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).bfloat16().float()
     go = torch.randn(B, Co, H, W, generator=g).bfloat16().float()

@@ -30,7 +30,7 @@ def _count(names):
     return {n: lib.jspsr_launch_count(n.encode()) for n in names}
 
 
-KERNELS = ("conv64_resident", "conv_patch_16x16", "conv_patch", "conv_igemm", "conv2d_wgrad_patch", "conv2d_wgrad",
+KERNELS = ("conv64_resident", "conv128_resident", "conv_patch_16x16", "conv_patch", "conv_igemm", "conv2d_wgrad_patch", "conv2d_wgrad",
            "head_forward", "head_backward", "prop_logits_forward (dma)", "prop_logits_backward (dma)",
            "prop_head_forward", "prop_head_backward", "prop_head_forward (dma)", "prop_head_backward (dma)")
 
@@ -75,6 +75,7 @@ def test_benched_architecture_at_a_kernel_selecting_size():
     assert used[torch.bfloat16]["conv_patch_16x16"] >= 1 and used[torch.float32]["conv_patch_16x16"] >= 1, used
     assert used[torch.bfloat16]["conv2d_wgrad_patch"] >= 20 and used[torch.float32]["conv2d_wgrad_patch"] >= 20, used
     assert used[torch.float32]["conv64_resident"] == 0          # K2r is the bf16 kernel
+    assert used[torch.bfloat16]["conv128_resident"] >= 2 and used[torch.float32]["conv128_resident"] == 0, used      # K2q: conv1 of the 128-channel blocks, both ways
     # the propagation step, either storage type: the heads write fp32 planes (K1c) and the persistent LDS-DMA kernel of the
     # public boundary reads them (round 4) -- the 32-channel NHWC head kernels of rounds 2-3 are not launched
     for dt in (torch.float32, torch.bfloat16):

@@ -47,6 +47,22 @@ def timing():
         wpt = K.pack_weight(w, 1, 128, torch.bfloat16)
         add = torch.randn(B, H, W, 128, device="cuda").to(torch.bfloat16)
         flops = 2.0 * B * H * W * 128 * 128 * 9
+        # the size the dynamic tile queue runs at: forward (+ statistics) and data gradient against torch's fp32 convolution
+        import torch.nn.functional as F
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+        wr = w.to(torch.bfloat16).float()
+        ref = F.conv2d(xr, wr, None, 1, 1)
+        y, st = K.conv2d_forward(x, wp, None, 1, 1, stats=True)
+        rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+        e_y = rel(y.float().permute(0, 3, 1, 2), ref.detach())
+        e_s = rel(st.sum(0)[0], ref.detach().sum((0, 2, 3)))
+        e_q = rel(st.sum(0)[1], (ref.detach() ** 2).sum((0, 2, 3)))
+        ref.backward(x.float().permute(0, 3, 1, 2))
+        dx = K.conv2d_dgrad(x, wpt, (H, W), 1, 1, addend=add)
+        e_d = rel(dx.float().permute(0, 3, 1, 2), xr.grad.to(torch.bfloat16).float() + add.float().permute(0, 3, 1, 2))
+        print(f"  {B}x{H}x{W} vs torch fp32: fwd {e_y:.2e} sum {e_s:.2e} sumsq {e_q:.2e} dgrad+addend {e_d:.2e}", flush=True)
+        assert e_y < 6e-3 and e_s < 1e-3 and e_q < 1e-4 and e_d < 6e-3
+        del xr, ref, y, st, dx
         for name, fn in (("fwd", lambda: K.conv2d_forward(x, wp, None, 1, 1)),
                          ("fwd+stats", lambda: K.conv2d_forward(x, wp, None, 1, 1, stats=True)),
                          ("dgrad", lambda: K.conv2d_dgrad(x, wpt, (H, W), 1, 1)),
@@ -73,7 +89,7 @@ def main():
     os.makedirs("gpurun_out", exist_ok=True)
     outs = {}
     for tag, env in (("k2q", {"JSPSR_CONV_RESIDENT128": "1", "JSPSR_CONV_RESIDENT128_MIN": "1"}), ("patch", {"JSPSR_CONV_RESIDENT128": "0"})):
-        path = f"gpurun_out/k2q_{tag}.pt"
+        path = f"/tmp/k2q_{tag}.pt"
         print(f"== {tag}", flush=True)
         r = subprocess.run([sys.executable, __file__, "--child", path, "time"], env={**os.environ, **env}, timeout=900)
         if r.returncode:
