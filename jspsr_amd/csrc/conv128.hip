@@ -13,11 +13,12 @@
 //   * tiles of 8 x 16 pixels; every wave multiplies ALL 128 pixels of the tile by its slice: one ds_read_b128 of a
 //     16-pixel x 32-channel patch fragment feeds 4 MFMAs (the wave's 4 channel blocks) -- a quarter of the LDS read bytes
 //     per flop of the patch kernel, no weight bytes through LDS at all, no stage barriers;
-//   * the two K-halves of a channel group meet once per tile: each wave hands the partial sums of the 4 tile rows its
-//     partner finishes to the partner's inbox in LDS (16 KB, lane-linear ds_write_b128 / ds_read_b128) and finishes its own
-//     4 rows x 64 channels from registers.  Operands are swapped (A = weights), so a lane holds 16 channels of one pixel:
-//     the weight rows are assigned to MFMA rows such that those are two runs of 8 contiguous channels -> two 16-byte NHWC
-//     stores per pixel, no cross-lane traffic;
+//   * the two K-halves of a channel group meet once per tile, in the MIDDLE of the tap loop: a wave first multiplies the 4 tile
+//     rows its partner finishes, writes their partial sums to the partner's inbox in LDS (16 KB, lane-linear ds_write_b128),
+//     and after one barrier starts the 4 rows it finishes itself FROM the partner's partial sums (ds_read_b128 straight into
+//     the accumulators: no addition pass, no zero start).  Operands are swapped (A = weights), so a lane holds 16 channels of
+//     one pixel: the weight rows are assigned to MFMA rows such that those are two runs of 8 contiguous channels -> two
+//     16-byte NHWC stores per pixel, no cross-lane traffic;
 //   * the 10 x 18-pixel input patch (46 080 B) of tile t+1 arrives by LDS-DMA (45 pieces of 1 KiB, interleaved with
 //     the tap loop of tile t) into the other patch buffer.  LDS image: 256 B per pixel, NO padding -- 16-byte chunk c of
 //     patch pixel P sits at chunk position c ^ 2 (P & 7): the DMA writes lane-linear, so the swizzle is applied on the
@@ -29,7 +30,17 @@
 //   * BatchNorm statistics (training forward): per-channel sums over a lane's four pixels are in-lane adds, the 16 pixel
 //     columns are the 16 lanes of a DPP row (4 row_ror adds per value), the two K-half waves fold through 2 KB of LDS and
 //     one of them writes the tile's row of the partial-statistics buffer one period later.
-// LDS: 2 x 46 080 (patches, at 0 and 65 536) + 4 x 16 384 (inboxes) + 2 048 (statistics fold) of 163 840 bytes.
+// LDS: 2 x 46 080 (patches, at 0 and 65 536) + 4 x 16 384 (inboxes) + 2 048 (statistics fold) + 1 024 (dump) of 163 840 bytes.
+// The MFMAs are issued from inline asm ("a" constraints: the register allocator keeps MFMA A/B operands in VGPRs whatever the
+// pressure and spills the rest of the weights to scratch), which also fixes their order against the fragment reads and the
+// DMA pieces; two hazards the compiler does not see inside an asm statement are covered by hand (s_nop after the last MFMA
+// before its result is read; s_nop 4 before a vector-memory instruction whose SGPR operand a VALU instruction may have
+// written -- the cause of a memory fault in the first version of the dynamic walk).
+// Where a wave's cycles go (in-kernel stamps, tools/lab/k2q_stamps.py, 8 x 512^2, ~2.0 GHz held): 15 900 per tile against
+// 9 216 of bare MFMA issue -- the tap loop 12 400 (9 970 with no patch traffic at all: ~165 cycles per LDS-DMA piece,
+// the same when the pieces are staged through registers instead (K2Q_DMA_MODE 3), wherever they are placed, and whether their
+// address arithmetic is 25 instructions or 3), the meeting ~1 500, the epilogue 1 750 (+ 2 300 with statistics, + 1 200 with
+// an addend).  With ONE wave per SIMD nothing overlaps these; two waves per SIMD do not fit the weights.
 // Out-of-image patch pixels fail the buffer descriptor's range check and land as zeros (the conv's zero padding).
 #include "conv_igemm.h"
 
@@ -65,8 +76,17 @@ constexpr int Q_ROWS4 = 4 * Q_PW * Q_PIXB;                  // four patch rows: 
 #define K2Q_LA 4      // patch fragments requested ahead of their MFMAs (lab builds: -DK2Q_LA=n)
 #endif
 #ifndef K2Q_DMA_MODE
-#define K2Q_DMA_MODE 1   // 0: all pieces before the tap loop; 1: interleaved with it
+#define K2Q_DMA_MODE 1   // 0: all LDS-DMA pieces before the tap loop; 1: interleaved with it; 2: none (timing lab: WRONG results);
+#endif                   // 3: pieces staged through registers (buffer_load -> VGPR -> ds_write_b128), interleaved
+#ifndef K2Q_LD_EVERY
+#define K2Q_LD_EVERY 9    // mode 3: a piece is requested every so many fragment reads ...
 #endif
+#ifndef K2Q_LD_DIST
+#define K2Q_LD_DIST 27    // ... and written to LDS this many reads later (three pieces = 12 registers in flight)
+#endif
+#ifndef K2Q_DMA_EVERY
+#define K2Q_DMA_EVERY 6  // a piece every so many fragment reads (>= 6: the two stages of a piece sit 3 reads apart), from the start of
+#endif                   // the tap loop: the last of the 12 is requested half a tile before the wait for it (4 .. 12 measured equal)
 constexpr int Q_NK = 144, Q_LAH = K2Q_LA;                   // fragment reads per tile and wave; look-ahead
 
 __device__ __forceinline__ int inbox_off(int wave) { return wave == 0 ? Q_PATCHB : Q_BUF1 + Q_PATCHB + (wave - 1) * Q_XCHB; }
@@ -117,8 +137,10 @@ __device__ __forceinline__ void mfma4(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3
 #undef K2Q_MFMA4
 }
 
+typedef const i32x4 __attribute__((address_space(3)))* lds_frag_t;      // a patch fragment by its LDS address (no generic-pointer base add per read)
+
 struct QTile { int bimg, tyi, txi; };
-struct QSrc { i32x4 desc; int oy0, ox0; };
+struct QSrc { i32x4 desc; __amdgpu_buffer_rsrc_t rsrc; int oy0, ox0; bool interior; };
 
 template <int SIGN, int MODE, int KH>      // MODE 0: plain (+ addend / ReLU), 1: + BatchNorm statistics
 __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt, __bf16* __restrict__ out,
@@ -130,6 +152,7 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
   const int ttx = (g.MW + Q_TW - 1) / Q_TW, tty = (g.MH + Q_TH - 1) / Q_TH;
   const int G = gridDim.x;
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+  if (lds0 != 0) __builtin_trap();      // the XOR steps of the fragment addresses (k-step: 64, patch buffer: 65 536) assume the dynamic segment starts at 0: this kernel has no static LDS
   const int v = xcd_contiguous(blockIdx.x, G);
 
   // ---- weights: 72 A-operands (9 taps x 2 k-steps x 4 channel blocks), once -------------------------------------------------
@@ -169,6 +192,8 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     const unsigned long long b64 = reinterpret_cast<unsigned long long>(in) + (opix0 * g.in_cstride + g.in_coff) * 2;
     // no next tile: an empty descriptor -- every lane fails the range check and the pieces land as zeros in the idle buffer
     p.desc = i32x4{(int)(unsigned)b64, (int)((unsigned)(b64 >> 32) & 0xffffu), more ? (int)0xFFFFFF00u : 0, 0x00020000};
+    p.interior = p.oy0 >= 0 && p.ox0 >= 0 && p.oy0 + Q_PH <= g.IH && p.ox0 + Q_PW <= g.IW;    // wave-uniform
+    p.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(b64), 0, more ? 0xFFFFFF00u : 0u, 0x00020000);
     return p;
   };
   // (s_nop 4 between the M0 write and the DMA: 1 wait state for M0, 5 for a descriptor SGPR that a VALU instruction -- a
@@ -181,16 +206,60 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
   // than kept in twelve registers; the swizzle term is the same for all pieces of a lane: 16 i = 0 (mod 8))
   const int p0lane = 4 * wave + q;
   const unsigned swz16 = (unsigned)((n ^ (2 * (p0lane & 7))) << 4);
-  auto issue_piece = [&](const QSrc& p, unsigned bufoff, int i) __attribute__((always_inline)) {
-    const bool have = wave + 4 * i < Q_PIECES;                  // wave-uniform; false only for the 12th piece of waves 1-3
+  // Two stages, a few tap-loop steps apart: with ONE wave per SIMD every VALU cycle beyond the ~36 an MFMA group leaves free
+  // is a cycle the matrix pipe idles (measured with in-kernel stamps: the one-piece arithmetic the compiler made of the plain
+  // expression -- two quarter-rate v_mad_u64_u32 and an EXEC-masked block around them -- cost 180 cycles per piece, 2 150 of
+  // a 12 500-cycle tap loop).  24-bit multiplies (full rate), each kept apart from the add behind it by an empty asm, no
+  // branch; the first stage ends in an asm that pins its three results before the next MFMA group.
+  // Interior tiles (all but the image border's) take a lane's source offset of piece i from a register and issue the piece in
+  // three instructions; border tiles recompute the coordinates for the range test behind a scalar branch.
+  unsigned dsrc[Q_NP];
+#pragma unroll
+  for (int i = 0; i < Q_NP; ++i) {
+    const int P = p0lane + 16 * i, py = P / Q_PW, px = P - py * Q_PW;
+    dsrc[i] = (unsigned)((py * g.IW + px) * pix_bytes) + swz16;
+  }
+  struct PieceXY { int py, px; unsigned off; };
+  auto piece_xy = [&](int i) __attribute__((always_inline)) {       // tile-invariant, recomputed: patch pixel of this lane in piece i
     int p0 = p0lane;
-    asm volatile("" : "+v"(p0));                               // opaque: the compiler must not hoist twelve sets of tile-invariant coordinates into registers
+    asm volatile("" : "+v"(p0));                               // opaque: the compiler must not hoist twelve sets of coordinates into registers
     const int P = p0 + 16 * i;
-    const int py = (int)(__umul24(P, 3641) >> 16), px = P - (int)__umul24(py, Q_PW);        // P / 18 for P < 400
-    const bool in_img = (unsigned)(p.oy0 + py) < (unsigned)g.IH && (unsigned)(p.ox0 + px) < (unsigned)g.IW;
-    const unsigned src = in_img ? (unsigned)((py * g.IW + px) * pix_bytes) + swz16 : 0xFFFFFFF0u;
-    const unsigned dst = lds0 + (have ? bufoff + (unsigned)(wave + 4 * i) * 1024u : (unsigned)Q_OFF_DUMP);
+    PieceXY c;
+    c.py = (int)(__umul24(P, 3641) >> 16);                     // P / 18 for P < 400
+    unsigned t = __umul24(c.py, Q_PW);
+    asm("" : "+v"(t));
+    c.px = P - (int)t;
+    unsigned t2 = __umul24(c.py, g.IW);                        // 10 IW + 18 and the pixel pitch are < 2^24 (conv128_resident_ok)
+    asm("" : "+v"(t2));
+    c.off = t2 + (unsigned)c.px;
+    asm volatile("" : "+v"(c.py), "+v"(c.px), "+v"(c.off));
+    return c;
+  };
+  auto piece_src = [&](const QSrc& p, const PieceXY& c) __attribute__((always_inline)) {
+    unsigned b = __umul24(c.off, pix_bytes);
+    asm("" : "+v"(b));
+    unsigned src = b + swz16;
+    src = (unsigned)(p.oy0 + c.py) < (unsigned)g.IH ? src : 0xFFFFFFF0u;
+    src = (unsigned)(p.ox0 + c.px) < (unsigned)g.IW ? src : 0xFFFFFFF0u;
+    return src;
+  };
+  auto piece_dst = [&](unsigned bufoff, int i) __attribute__((always_inline)) {      // wave-uniform; the dump for the 12th piece of waves 1-3
+#ifdef K2Q_LAB_TODUMP      // timing lab (WRONG results): every piece is fetched and lands in the dump -- the traffic without new patch data
+    return (unsigned)Q_OFF_DUMP;
+#endif
+    return (wave + 4 * i < Q_PIECES) ? bufoff + (unsigned)(wave + 4 * i) * 1024u : (unsigned)Q_OFF_DUMP;
+  };
+  auto issue_piece = [&](const QSrc& p, unsigned bufoff, int i) __attribute__((always_inline)) {
+    unsigned src = dsrc[i];
+    if (!p.interior) src = piece_src(p, piece_xy(i));
+    const unsigned dst = lds0 + piece_dst(bufoff, i);
+#if defined(K2Q_LAB_NOISSUE)      // timing lab (WRONG results): the address arithmetic without the DMA instruction
+    asm volatile("" : : "s"(dst), "v"(src), "s"(p.desc));
+#elif defined(K2Q_LAB_OOB)        // timing lab (WRONG results): the DMA instruction with every lane out of range -- zeros land, nothing is fetched
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src | 0xF0000000u), "s"(p.desc));
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(dst), "v"(src), "s"(p.desc));
+#endif
   };
 
   // ---- patch-fragment plan: lane (n, q) reads chunk 8 KH + 4 s + q of patch pixel 18 R + tx + n ---------------------------------
@@ -212,46 +281,69 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds0 + (unsigned)Q_OFF_DUMP), "v"(off), "s"(d));
   };
 
-  // ---- the tap loop: 144 fragment reads x 4 MFMAs, weights from registers -----------------------------------------------------
-  f32x4 acc[8][4];
-  auto mfma_tile = [&](const QSrc& nxt, unsigned nbufoff, QTile tc) __attribute__((always_inline)) {
-    i32x4 a[Q_LAH];
-    static_for<0, Q_NK + Q_LAH>([&](auto K) __attribute__((always_inline)) {
-      constexpr int k = decltype(K)::value;
-      if constexpr (k >= Q_LAH) {        // consumes ring slot k % LA before the read below refills it
-        constexpr int kk = k - Q_LAH, tap = kk >> 4, s = (kk >> 3) & 1, r = kk & 7;
-        // taps 0-7: weights in AGPRs (64 operands = all 256 of them), tap 8: in VGPRs
-        mfma4<(kk < 8), (kk < 128)>(acc[r][0], acc[r][1], acc[r][2], acc[r][3], breg[tap][s][0], breg[tap][s][1], breg[tap][s][2],
-                                    breg[tap][s][3], a[kk % Q_LAH]);
-      }
-      if constexpr (k < Q_NK) {
-        constexpr int tap = k >> 4, s = (k >> 3) & 1, r = k & 7;
-        constexpr int ty = SIGN > 0 ? tap / 3 : 2 - tap / 3, tx = SIGN > 0 ? tap % 3 : 2 - tap % 3;
-        constexpr int R = r + ty;
-        a[k % Q_LAH] = *reinterpret_cast<const i32x4*>(smem + ((abase[R & 3][tx] ^ (unsigned)(s * 64)) + (unsigned)((R >> 2) * Q_ROWS4)));
-        if constexpr (K2Q_DMA_MODE == 1 && k % 12 == 5) issue_piece(nxt, nbufoff, k / 12);
-        if constexpr (!STATS && k == 1) prefetch_addend(tc);
-      }
-    });
-    // the accumulators are read by ordinary instructions next: the compiler does not know an MFMA wrote them
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  };
-
-  // ---- hand-over of the partner's rows, own rows completed ---------------------------------------------------------------------
-  // tile rows 4 KH .. 4 KH + 3 are this wave's to finish; the other four go to wave ^ 2 (same channels, other K-half)
+  // ---- the two K-halves of a channel group meet in the MIDDLE of the tap loop ----------------------------------------------------
+  // tile rows 4 KH .. 4 KH + 3 are this wave's to finish; the other four go to wave ^ 2 (same channels, other K-half).  A wave
+  // multiplies the rows it gives away FIRST, writes their partial sums to the partner's inbox, and after one barrier starts the
+  // rows it keeps FROM the partner's partial sums (the inbox is read straight into the accumulators: no addition pass, no
+  // zero start) -- with one wave per SIMD every instruction that is not an MFMA is time the matrix pipe idles.
   char* const give = smem + inbox_off(wave ^ 2) + lane * 16;
   const char* const take = smem + inbox_off(wave) + lane * 16;
-  auto hand_over = [&]() __attribute__((always_inline)) {
+  f32x4 acc[8][4];
+  auto meet = [&]() __attribute__((always_inline)) {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the accumulators are read by ordinary instructions next: the compiler does not know an MFMA wrote them
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) *reinterpret_cast<f32x4*>(give + (i * 4 + cb) * 1024) = acc[4 * (1 - KH) + i][cb];
-  };
-  auto take_over = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[4 * KH + i][cb] += *reinterpret_cast<const f32x4*>(take + (i * 4 + cb) * 1024);
+      for (int cb = 0; cb < 4; ++cb) acc[4 * KH + i][cb] = *reinterpret_cast<const f32x4*>(take + (i * 4 + cb) * 1024);
+  };
+
+  // ---- the tap loop: 144 fragment reads x 4 MFMAs, weights from registers -----------------------------------------------------
+  auto mfma_tile = [&](const QSrc& nxt, unsigned nbufoff, QTile tc) __attribute__((always_inline)) {
+    i32x4 a[Q_LAH];
+    constexpr int NSTG = (K2Q_LD_DIST + K2Q_LD_EVERY - 1) / K2Q_LD_EVERY;
+    u32x4 stg[NSTG];       // mode 3: pieces on their way from memory to LDS
+    static_for<0, Q_NK + Q_LAH>([&](auto K) __attribute__((always_inline)) {
+      constexpr int k = decltype(K)::value;
+      // step kk: half = kk / 72 (0: the rows given away, 1: the rows kept), then 18 (tap, k-step) pairs x 4 rows
+      if constexpr (k >= Q_LAH) {        // consumes ring slot k % LA before the read below refills it
+        constexpr int kk = k - Q_LAH, half = kk / 72, st = (kk % 72) >> 2, tap = st >> 1, s = st & 1;
+        constexpr int r = (half == 0 ? 4 * (1 - KH) : 4 * KH) + (kk & 3);
+        if constexpr (kk == 72) meet();
+        // taps 0-7: weights in AGPRs (64 operands = all 256 of them), tap 8: in VGPRs
+        mfma4<(half == 0 && st == 0), (tap < 8)>(acc[r][0], acc[r][1], acc[r][2], acc[r][3], breg[tap][s][0], breg[tap][s][1], breg[tap][s][2],
+                                                 breg[tap][s][3], a[kk % Q_LAH]);
+      }
+      if constexpr (k < Q_NK) {
+        constexpr int half = k / 72, st = (k % 72) >> 2, tap = st >> 1, s = st & 1;
+        constexpr int r = (half == 0 ? 4 * (1 - KH) : 4 * KH) + (k & 3);
+        constexpr int ty = SIGN > 0 ? tap / 3 : 2 - tap / 3, tx = SIGN > 0 ? tap % 3 : 2 - tap % 3;
+        constexpr int R = r + ty;
+        a[k % Q_LAH] = *reinterpret_cast<lds_frag_t>((abase[R & 3][tx] ^ (unsigned)(s * 64)) + (unsigned)((R >> 2) * Q_ROWS4));
+        if constexpr (K2Q_DMA_MODE == 1 && k % K2Q_DMA_EVERY == 2 && k / K2Q_DMA_EVERY < Q_NP) issue_piece(nxt, nbufoff, k / K2Q_DMA_EVERY);
+        if constexpr (!STATS && k == 1) prefetch_addend(tc);
+        if constexpr (K2Q_DMA_MODE == 3) {
+          constexpr int LD = K2Q_LD_EVERY, WD = K2Q_LD_DIST;
+          static_assert(2 + LD * (Q_NP - 1) + WD < Q_NK, "the last piece is written inside the loop");
+          if constexpr (k >= 2 + WD && (k - 2 - WD) % LD == 0 && (k - 2 - WD) / LD < Q_NP) {
+            constexpr int j = (k - 2 - WD) / LD;
+            *reinterpret_cast<u32x4*>(smem + piece_dst(nbufoff, j) + lane * 16) = stg[j % NSTG];
+          }
+          if constexpr (k >= 2 && (k - 2) % LD == 0 && (k - 2) / LD < Q_NP) {
+            constexpr int j = (k - 2) / LD;
+            stg[j % NSTG] = __builtin_amdgcn_raw_buffer_load_b128(nxt.rsrc, piece_src(nxt, piece_xy(j)), 0, 0);
+          }
+        }
+      }
+    });
+    // the accumulators are read by ordinary instructions next: the compiler does not know an MFMA wrote them
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   };
 
   const bool relu_first = g.relu && !g.addend, relu_last = g.relu && g.addend;
@@ -279,13 +371,6 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
       const unsigned pix = (unsigned)(y * g.OW + x);
       ooff[i] = inside[i] ? pix * (unsigned)(g.out_cstride * 2) + q * 16u : 0xFFFFFFF0u;
       aoff[i] = inside[i] ? pix * (unsigned)(g.add_cstride * 2) + q * 16u : 0xFFFFFFF0u;
-    }
-    u32x4 av[4][2];
-    if (!STATS && g.addend) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) av[i][h] = __builtin_amdgcn_raw_buffer_load_b128(adrsrc, aoff[i], h * 64, 0);
     }
     if constexpr (STATS) {
       if (stats) {
@@ -333,23 +418,42 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
         }
       }
     }
-    if (!STATS && relu_first) {      // wave-uniform
+    // Two whole branches (wave-uniform): the addend loads are issued AND consumed inside one of them.  (Issued under one `if`
+    // and consumed under another, the compiler's wait-count bookkeeping carries them as possibly pending into the next
+    // tile, whose first MFMAs overwrite their registers: it then waits at the head of every tap loop with a small vmcnt --
+    // for the stores of the tile before.)
+    if (!STATS && g.addend) {
+      u32x4 av[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int h = 0; h < 2; ++h) av[i][h] = __builtin_amdgcn_raw_buffer_load_b128(adrsrc, aoff[i], h * 64, 0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[4 * KH + i][cb][j] = relu_bits(acc[4 * KH + i][cb][j]);
-    }
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 lo = acc[4 * KH + i][2 * h], hi = acc[4 * KH + i][2 * h + 1];
+          const u32x4 o = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(add_bf16x8(o, av[i][h], relu_last), orsrc, ooff[i], h * 64, 0);
+        }
+    } else {
+      if (!STATS && relu_first) {      // wave-uniform
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 lo = acc[4 * KH + i][2 * h], hi = acc[4 * KH + i][2 * h + 1];
-        u32x4 o = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
-        if (!STATS && g.addend) o = add_bf16x8(o, av[i][h], relu_last);
-        __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[i], h * 64, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * KH + i][cb][j] = relu_bits(acc[4 * KH + i][cb][j]);
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 lo = acc[4 * KH + i][2 * h], hi = acc[4 * KH + i][2 * h + 1];
+          const u32x4 o = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, ooff[i], h * 64, 0);
+        }
+    }
   };
   // the tile's row of the partial-statistics buffer (rows are 8 x 16-pixel tiles: jspsr_conv2d_stats_rows), one period late
   auto flush_stats = [&](QTile tc) __attribute__((always_inline)) {
@@ -389,12 +493,23 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
   // every tile would wait there for the stores of the tile before)
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
   asm volatile("" ::: "memory");
+#ifdef K2Q_STAMPS      // lab build: cycles per phase, printed by waves 0 and 2 of workgroup 0 (tools/lab/build_k2q_variants.sh stamps=-DK2Q_STAMPS)
+  unsigned long long st_bar = 0, st_mfma = 0, st_epi = 0, st_vm = 0, s0, s1;
+  const unsigned long long c_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
+#define K2Q_STAMP(acc_) do { s1 = __builtin_readcyclecounter(); acc_ += s1 - s0; s0 = s1; } while (0)
+#else
+#define K2Q_STAMP(acc_) do { } while (0)
+#endif
   for (; t < ntiles; ++it) {
+#ifdef K2Q_STAMPS
+    s0 = __builtin_readcyclecounter();
+#endif
     // every wave has waited for its own pieces of this patch (below); once all have arrived it is complete, nobody reads
     // the other patch buffer or an inbox any more
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    K2Q_STAMP(st_bar);
     if (STATS && stats && it > 0) flush_stats(tprev);
     int tn, kn = 0, nn = nrun;
     QTile tnext;
@@ -428,12 +543,9 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
       for (int i = 0; i < Q_NP; ++i) issue_piece(nxt, bufoff ^ Q_BUF1, i);
     }
     mfma_tile(nxt, bufoff ^ Q_BUF1, tcur);
-    hand_over();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    take_over();
+    K2Q_STAMP(st_mfma);
     epilogue(tcur);
+    K2Q_STAMP(st_epi);
     // the other patch buffer next: one XOR per base register
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -443,11 +555,19 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     // this wave's pieces of the next patch have landed once all but its 8 youngest vector-memory operations (the stores of
     // the epilogue; the pieces and the addend loads are older) are done
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    K2Q_STAMP(st_vm);
     if (dyn && tid == 0 && pend_slot >= 0) { s_run[pend_slot] = (int)pend; pend_slot = -1; }
     tprev = tcur;
     tcur = tnext;
     t = tn; krun = kn; nrun = nn;
   }
+#ifdef K2Q_STAMPS
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 2) && it > 0) {
+    const unsigned long long dc = __builtin_readcyclecounter() - c_begin, dr = __builtin_amdgcn_s_memrealtime() - r_begin;
+    printf("K2Q wave %d tiles %d: barrier %llu  tap loop incl. the meeting %llu  epilogue %llu  vmcnt %llu (cycles per tile); clock %.0f MHz\n",
+           wave, it, st_bar / it, st_mfma / it, st_epi / it, st_vm / it, 100.0 * (double)dc / (double)dr);
+  }
+#endif
   if (dyn && tid == 0) {
     // last workgroup out re-arms the ticket for the launch that gets this slot next (1024 launches from now); every draw of
     // this workgroup has returned before it signs off
@@ -518,7 +638,7 @@ bool conv128_resident_ok(const ConvGeom& g, const void* in, const void* wgt, con
   if (g.in_cstride % 8 || g.in_coff % 8 || g.out_cstride % 8 || g.out_coff % 8) return false;
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;
-  if ((long long)(g.IW + 20) * 12 * g.in_cstride * 2 >= 0x7fffffffLL) return false;    // 32-bit offsets inside a patch
+  if ((long long)(g.IW + 20) * 12 * g.in_cstride * 2 >= 0x7fffffffLL || g.IW >= (1 << 20) || g.in_cstride >= (1 << 20)) return false;    // 32-bit offsets inside a patch, 24-bit factors
   if ((long long)g.OH * g.OW * g.out_cstride * 2 >= 0xF0000000LL || (long long)g.OH * g.OW * g.add_cstride * 2 >= 0xF0000000LL)
     return false;                                                                       // ... and inside one image of the result
   const long long tiles = (long long)g.B * ((g.MH + Q_TH - 1) / Q_TH) * ((g.MW + Q_TW - 1) / Q_TW);
@@ -536,6 +656,10 @@ int launch_conv128_resident(const void* in, const void* wgt, void* out, float* s
     ncu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }
   const int grid = ntiles < ncu ? ntiles : ncu;
+  static const int trace = [] { const char* e = getenv("JSPSR_CONV_TRACE128"); return e ? atoi(e) : 0; }();      // lab: the geometry of each launch
+  if (trace)
+    fprintf(stderr, "K2q sign %d B %d %dx%d in pitch %d off %d out pitch %d off %d addend %d (pitch %d) relu %d stats %d in %p out %p\n", g.sign, g.B,
+            g.MH, g.MW, g.in_cstride, g.in_coff, g.out_cstride, g.out_coff, g.addend != nullptr, g.add_cstride, g.relu, stats != nullptr, in, out);
   if (g.sign > 0) {
     if (stats) launch_k2q<1, 1>(in, wgt, out, stats, g, ntiles, grid, s);
     else launch_k2q<1, 0>(in, wgt, out, stats, g, ntiles, grid, s);
