@@ -30,10 +30,18 @@ typedef void* jspsr_stream_t; /* hipStream_t */
 /* ABI version of this header (bumped on any signature change). */
 int jspsr_abi_version(void);
 /* Diagnostics: launches so far (this process) of the kernel family named `what` -- the names the error texts use:
- * "conv64_resident" (K2r), "conv_patch", "conv_patch_16x16", "conv_igemm", "conv2d_wgrad_patch", "prop_forward (dma)",
+ * "conv64_resident" (K2r), "conv128_resident" (K2q), "conv_patch", "conv_patch_16x16", "conv_igemm", "conv2d_wgrad_patch", "prop_forward (dma)",
  * "prop_backward (dma)", "prop_forward", "prop_head_forward", ...  Lets a parity test assert that a shape really took
  * the kernel it is meant to exercise.  -1 for a NULL name, 0 for a name never launched. */
 long long jspsr_launch_count(const char* what);
+/* The persistent register-resident conv kernels (K2r: "conv64_resident", K2q: "conv128_resident") hand their tiles out either
+ * by a static stride walk (default alone on the GPU: neighbouring tiles share an XCD's L2) or from a global ticket in runs of
+ * four (on = 1).  One workgroup of these kernels needs a WHOLE compute unit; where another kernel holds some CUs for long --
+ * RCCL's all-reduce beside the backward pass of a data-parallel step -- the workgroups that start late would, with the static
+ * walk, still do their full share after everybody else has finished; drawing from the ticket they find it empty and leave.
+ * on = -1: back to the environment's default (JSPSR_CONV_DYNQ / JSPSR_CONV_DYNQ128).  Returns the previous setting.
+ * jspsr_amd.ddp.GradReducer switches it on for world sizes > 1.  (ABI v15) */
+int jspsr_conv_dynamic_queue(int on);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* jspsr_last_error(void);
 

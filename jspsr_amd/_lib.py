@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("JSPSR_LAB_LIB") or os.path.join(_HERE, "lib", "libjspsr_hip.so")  # JSPSR_LAB_LIB: kernel-lab builds only
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lock = threading.Lock()
 _lib = None
@@ -26,6 +26,7 @@ c_ll = ctypes.c_longlong
 SIGNATURES = {
     "jspsr_abi_version": (c_i, []),
     "jspsr_launch_count": (c_ll, [ctypes.c_char_p]),
+    "jspsr_conv_dynamic_queue": (c_i, [c_i]),
     "jspsr_last_error": (ctypes.c_char_p, []),
     "jspsr_prop_forward_f32": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
     "jspsr_prop_backward_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),

@@ -13,6 +13,7 @@ namespace jspsr {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+int conv_dynq_override();      // jspsr_conv_dynamic_queue(): -1 = the environment's default, 0 / 1 = forced
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }

@@ -50,7 +50,13 @@ int check_launch(const char* what) {
 
 }  // namespace jspsr
 
-extern "C" int jspsr_abi_version(void) { return 14; }
+namespace jspsr {
+std::atomic<int> g_conv_dynq{-1};
+int conv_dynq_override() { return g_conv_dynq.load(std::memory_order_relaxed); }
+}  // namespace jspsr
+
+extern "C" int jspsr_abi_version(void) { return 15; }
+extern "C" int jspsr_conv_dynamic_queue(int on) { return jspsr::g_conv_dynq.exchange(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
 extern "C" long long jspsr_launch_count(const char* what) {
   if (!what) return -1;
   long long n = 0;

@@ -619,7 +619,8 @@ void launch_k2q(const void* in, const void* wgt, void* out, float* stats, const 
   // are per-lane values to the compiler, and neighbouring tiles no longer share an XCD's L2); in the multi-stream step
   // 63.6 / 64.3 / 64.4 ms static against 63.1 / 64.3 / 64.4 dynamic, three interleaved runs each -- no difference.
   static const int dynq = [] { const char* e = getenv("JSPSR_CONV_DYNQ128"); return e ? atoi(e) : 0; }();
-  unsigned* ticket = (dynq && (long long)ntiles >= 4LL * Q_RUN * grid) ? next_ticket() : nullptr;
+  const int forced = conv_dynq_override();      // jspsr_conv_dynamic_queue(): data-parallel runs switch the queue on (RCCL holds CUs beside the backward pass)
+  unsigned* ticket = ((forced >= 0 ? forced : dynq) && (long long)ntiles >= 4LL * Q_RUN * grid) ? next_ticket() : nullptr;
   hipLaunchKernelGGL((conv128_resident_kernel<SIGN, MODE>), dim3(grid), dim3(Q_NTH), Q_LDS, s, static_cast<const __bf16*>(in),
                      static_cast<const __bf16*>(wgt), static_cast<__bf16*>(out), stats, g, ntiles, ticket);
 }

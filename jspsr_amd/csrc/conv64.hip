@@ -556,7 +556,8 @@ void launch_k2r(const void* in, const void* wgt, const float* bias, void* out, f
   // multi-stream step on one box, three interleaved runs each: 65.9 / 64.2 / 65.5 ms static, 68.0 / 66.3 / 65.4 ms dynamic
   // (profiles/r03_k2r_dynamic_queue_ab.txt) -- the late workgroups the queue relieves were not what the step waits for.
   static const int dynq = [] { const char* e = getenv("JSPSR_CONV_DYNQ"); return e ? atoi(e) : 0; }();
-  unsigned* ticket = (dynq && (long long)ntiles >= 4LL * R_RUN * grid) ? next_ticket() : nullptr;
+  const int forced = conv_dynq_override();      // jspsr_conv_dynamic_queue(): data-parallel runs switch the queue on (RCCL holds CUs beside the backward pass)
+  unsigned* ticket = ((forced >= 0 ? forced : dynq) && (long long)ntiles >= 4LL * R_RUN * grid) ? next_ticket() : nullptr;
   constexpr int lds = MODE == 1 ? R_LDS_STATS : (MODE == 2 ? R_LDS_AFFINE : R_LDS_PLAIN);
   static bool attr_set = false;
   if (!attr_set) {

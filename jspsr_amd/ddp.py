@@ -26,6 +26,11 @@ class GradReducer:
         self.world = world if world is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
         total = sum(p.numel() for p in self.params)
         p0 = self.params[0]
+        if self.world > 1 and p0.is_cuda and dist.is_initialized():
+            # RCCL's all-reduce kernels hold compute units beside the backward pass; the persistent register-resident conv
+            # kernels need whole CUs: let their late workgroups find an empty tile queue instead of a full static share
+            from . import _lib
+            _lib.load().jspsr_conv_dynamic_queue(1)
         self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
         # reverse order = gradient production order; contiguous bucket ranges in the flat buffer
         self.buckets = []  # (start, end, n_params)

@@ -246,6 +246,35 @@ def test_conv_resident_128_path(B, H, W):
     assert _relerr(_nchw(dx.float()), F.relu(xx.grad.bfloat16().double() + res.double())) < 6e-3
 
 
+def test_conv_dynamic_queue_switch_gives_the_same_bits():
+    """jspsr_conv_dynamic_queue(1) -- what GradReducer sets for world sizes > 1 -- makes K2r and K2q draw their tiles from a
+    global ticket instead of the static stride walk: a scheduling change only, every output bit and every statistics row
+    stays what it was."""
+    K = _k()
+    from jspsr_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    outs = {}
+    for C, shape in ((64, (4, 512, 512)), (128, (4, 256, 512))):      # 4096 tiles each: where the queue starts
+        x = torch.randn(*shape, C, generator=g).cuda().bfloat16()
+        w = (torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5).cuda()
+        wp, wpt = K.pack_weight(w, 0, C, torch.bfloat16), K.pack_weight(w, 1, C, torch.bfloat16)
+        for mode in (0, 1, 1, 0):
+            prev = lib.jspsr_conv_dynamic_queue(mode)
+            try:
+                y, st = K.conv2d_forward(x, wp, None, 1, 1, stats=True)
+                dx = K.conv2d_dgrad(x, wpt, shape[1:], 1, 1, addend=x)
+                torch.cuda.synchronize()
+            finally:
+                lib.jspsr_conv_dynamic_queue(-1)
+            assert prev == -1
+            if (C, 0) not in outs:
+                outs[(C, 0)] = (y, st, dx)
+            else:
+                for a, b in zip((y, st, dx), outs[(C, 0)]):
+                    assert torch.equal(a, b), (C, mode)
+
+
 def test_conv_resident_kernels_overlap_on_two_streams():
     """K2r is a persistent kernel (one workgroup per CU, most of the CU's LDS and registers) with no device-global state:
     launches of its three modes queued on two streams at once -- as the step's branch streams do -- must give the bits of
