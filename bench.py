@@ -636,6 +636,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if os.environ.get("JSPSR_BENCH_GC", "freeze") == "freeze":
+        # The interpreter's cyclic collector: a full (generation-2) pass over everything the process has built by now -- the
+        # modules, ~1 400 autograd nodes per step, the ctypes bindings -- takes tens of ms, and where it falls is an accident
+        # of allocation counts (measured on one box: 62.4 ms/step over the 20 steps behind 5 warm-up steps, 59.5 behind 25,
+        # 60.0 in every block of an otherwise identical loop at module level: tools/lab/step_blocks.py).  Collect now, at a
+        # step boundary, and move what survives to the permanent generation, as long-running training loops do; the
+        # collector stays ON for what the timed steps allocate.
+        import gc
+        gc.collect()
+        gc.freeze()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
