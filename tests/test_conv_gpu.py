@@ -246,6 +246,20 @@ def test_conv_resident_128_path(B, H, W):
     assert _relerr(_nchw(dx.float()), F.relu(xx.grad.bfloat16().double() + res.double())) < 6e-3
 
 
+def test_conv_resident_128_random_geometries():
+    """K2q on 30 random geometries in a child process (JSPSR_CONV_RESIDENT128_MIN=1: every size takes the kernel): rasters from
+    less than one tile to 256 x 512, ragged both ways, batch 1..5, channel slices of wider tensors on both sides, addend, ReLU,
+    the tile queue on and off -- forward, statistics (totals and per-tile rows), slice writes (nothing outside the slice is
+    touched) and data gradient against torch's fp32 convolution (tools/lab/k2q_fuzz.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lab", "k2q_fuzz.py"), "30", "7"], capture_output=True, text=True,
+                       timeout=600, cwd=root, env=dict(os.environ, JSPSR_CONV_RESIDENT128_MIN="1"))
+    assert r.returncode == 0 and "FUZZ OK: 30 cases" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_conv_dynamic_queue_switch_gives_the_same_bits():
     """jspsr_conv_dynamic_queue(1) -- what GradReducer sets for world sizes > 1 -- makes K2r and K2q draw their tiles from a
     global ticket instead of the static stride walk: a scheduling change only, every output bit and every statistics row
