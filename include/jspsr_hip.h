@@ -40,7 +40,8 @@ long long jspsr_launch_count(const char* what);
  * RCCL's all-reduce beside the backward pass of a data-parallel step -- the workgroups that start late would, with the static
  * walk, still do their full share after everybody else has finished; drawing from the ticket they find it empty and leave.
  * on = -1: back to the environment's default (JSPSR_CONV_DYNQ / JSPSR_CONV_DYNQ128).  Returns the previous setting.
- * jspsr_amd.ddp.GradReducer switches it on for world sizes > 1.  (ABI v15) */
+ * jspsr_amd.ddp.GradReducer switches it on for world sizes > 1 -- a precaution (no multi-GPU box to measure it on; on one GPU
+ * the two walks time the same inside the step).  (ABI v15) */
 int jspsr_conv_dynamic_queue(int on);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* jspsr_last_error(void);
