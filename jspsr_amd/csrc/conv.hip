@@ -1100,7 +1100,7 @@ int launch(const void* in, const void* wgt, const float* bias, void* out, float*
   if constexpr (sizeof(T) == 2)
   {
     if (conv64_resident_ok(g, in, wgt, bias, out)) return launch_conv64_resident(in, wgt, bias, out, stats, g, s);
-    if (conv128_resident_ok(g, in, wgt, bias, out)) return launch_conv128_resident(in, wgt, out, stats, g, s);
+    if (conv128_resident_ok(g, in, wgt, bias, out)) return launch_conv128_resident(in, wgt, bias, out, stats, g, s);
   }
   if ((!no_patch || g.in_affine) && g.iy_mul == 1 && g.ix_mul == 1 && g.nty >= 1 && g.ntx >= 1 && g.nty <= 3 && g.ntx <= 3 &&
       g.nty * g.ntx > 1 && g.Cin % BKT == 0 && (long long)(g.IW + 20) * 12 * g.in_cstride * (long long)sizeof(T) < 0xE0000000LL) {

@@ -69,7 +69,8 @@ constexpr int Q_OFF_RUN = Q_OFF_RED + 2048;                // two published run 
 static_assert(Q_OFF_RUN + 16 <= Q_BUF1, "run starts inside the first 64 KiB");
 constexpr int Q_RUN = 4;                                    // tiles per draw (x-neighbours: their halo columns stay in this XCD's L2)
 constexpr int Q_OFF_DUMP = Q_BUF1 + Q_PATCHB + 3 * Q_XCHB;  // 1 KiB nobody reads: where the piece a wave does not have lands
-constexpr int Q_LDS = Q_OFF_DUMP + 1024;                    // 161 792
+constexpr int Q_OFF_PAR = Q_OFF_DUMP + 1024;                // affine form: [2][128] floats, per-channel scale | bias
+constexpr int Q_LDS = Q_OFF_PAR + 1024;                     // 162 816
 static_assert(Q_LDS <= 163840, "LDS of one CU");
 constexpr int Q_ROWS4 = 4 * Q_PW * Q_PIXB;                  // four patch rows: 18 432 (an immediate offset)
 #ifndef K2Q_LA
@@ -142,10 +143,10 @@ typedef const i32x4 __attribute__((address_space(3)))* lds_frag_t;      // a pat
 struct QTile { int bimg, tyi, txi; };
 struct QSrc { i32x4 desc; __amdgpu_buffer_rsrc_t rsrc; int oy0, ox0; bool interior; };
 
-template <int SIGN, int MODE, int KH>      // MODE 0: plain (+ addend / ReLU), 1: + BatchNorm statistics
-__device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt, __bf16* __restrict__ out,
-                                             float* __restrict__ stats, const ConvGeom& g, int ntiles, unsigned* __restrict__ ticket, char* smem) {
-  constexpr bool STATS = MODE == 1;
+template <int SIGN, int MODE, int KH>      // MODE 0: plain (+ addend / ReLU), 1: + BatchNorm statistics, 2: + per-channel scale / bias
+__device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, const __bf16* __restrict__ wgt, const float* __restrict__ bias,
+                                             __bf16* __restrict__ out, float* __restrict__ stats, const ConvGeom& g, int ntiles, unsigned* __restrict__ ticket, char* smem) {
+  constexpr bool STATS = MODE == 1, AFFINE = MODE == 2;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int cg = wave & 1;                                  // (KH = wave >> 1)
   const int n = lane & 15, q = lane >> 4;
@@ -418,6 +419,20 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
         }
       }
     }
+    if constexpr (AFFINE) {      // acc * scale + bias for this lane's sixteen channels, from the table the prologue put in LDS
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float* tab = reinterpret_cast<const float*>(smem + Q_OFF_PAR) + 64 * cg + 32 * h + 8 * q;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(tab + 4 * u), b4 = *reinterpret_cast<const f32x4*>(tab + 128 + 4 * u);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * KH + i][2 * h + u][j] = acc[4 * KH + i][2 * h + u][j] * s4[j] + b4[j];
+        }
+      }
+    }
     // Two whole branches (wave-uniform): the addend loads are issued AND consumed inside one of them.  (Issued under one `if`
     // and consumed under another, the compiler's wait-count bookkeeping carries them as possibly pending into the next
     // tile, whose first MFMAs overwrite their registers: it then waits at the head of every tap loop with a small vmcnt --
@@ -461,6 +476,9 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     stats[((size_t)((tc.bimg * tty + tc.tyi) * ttx + tc.txi) * 2 + which) * 128 + col] = red[which * 128 + col] + red[(2 + which) * 128 + col];
   };
 
+  if constexpr (AFFINE) {      // absent scale -> 1, absent bias -> 0; visible to every wave after the first barrier of the loop
+    reinterpret_cast<float*>(smem + Q_OFF_PAR)[tid] = tid < 128 ? (g.scale ? g.scale[tid] : 1.f) : (bias ? bias[tid - 128] : 0.f);
+  }
   // Tile walk.  Static (ticket == nullptr): tile v, v + G, v + 2G ... -- fine alone on the chip.  Dynamic: the workgroups draw
   // runs of Q_RUN x-neighbouring tiles from one global ticket.  A workgroup of this kernel needs a WHOLE CU (all of its LDS,
   // every register of its four SIMDs): beside the weight-gradient kernels of the other streams some CUs come free late, and
@@ -586,12 +604,12 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
 
 template <int SIGN, int MODE>
 __global__ __launch_bounds__(Q_NTH) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv128_resident_kernel(
-    const __bf16* __restrict__ in, const __bf16* __restrict__ wgt, __bf16* __restrict__ out, float* __restrict__ stats, ConvGeom g,
-    int ntiles, unsigned* __restrict__ ticket) {
+    const __bf16* __restrict__ in, const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ out,
+    float* __restrict__ stats, ConvGeom g, int ntiles, unsigned* __restrict__ ticket) {
   extern __shared__ __attribute__((aligned(128))) char smem[];
   // the K-half of a wave decides which accumulators it keeps: compile-time per branch (wave-uniform, scalar branch)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) conv128_body<SIGN, MODE, 0>(in, wgt, out, stats, g, ntiles, ticket, smem);
-  else conv128_body<SIGN, MODE, 1>(in, wgt, out, stats, g, ntiles, ticket, smem);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) conv128_body<SIGN, MODE, 0>(in, wgt, bias, out, stats, g, ntiles, ticket, smem);
+  else conv128_body<SIGN, MODE, 1>(in, wgt, bias, out, stats, g, ntiles, ticket, smem);
 }
 
 // Tickets of the dynamic tile queue: (next tile, workgroups done) pairs, handed out round-robin per launch; the last
@@ -608,7 +626,7 @@ unsigned* next_ticket() {
 }
 
 template <int SIGN, int MODE>
-void launch_k2q(const void* in, const void* wgt, void* out, float* stats, const ConvGeom& g, int ntiles, int grid, hipStream_t s) {
+void launch_k2q(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, int ntiles, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv128_resident_kernel<SIGN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS);
@@ -622,7 +640,7 @@ void launch_k2q(const void* in, const void* wgt, void* out, float* stats, const 
   const int forced = conv_dynq_override();      // jspsr_conv_dynamic_queue(): data-parallel runs switch the queue on (RCCL holds CUs beside the backward pass)
   unsigned* ticket = ((forced >= 0 ? forced : dynq) && (long long)ntiles >= 4LL * Q_RUN * grid) ? next_ticket() : nullptr;
   hipLaunchKernelGGL((conv128_resident_kernel<SIGN, MODE>), dim3(grid), dim3(Q_NTH), Q_LDS, s, static_cast<const __bf16*>(in),
-                     static_cast<const __bf16*>(wgt), static_cast<__bf16*>(out), stats, g, ntiles, ticket);
+                     static_cast<const __bf16*>(wgt), bias, static_cast<__bf16*>(out), stats, g, ntiles, ticket);
 }
 
 }  // namespace
@@ -634,8 +652,9 @@ bool conv128_resident_ok(const ConvGeom& g, const void* in, const void* wgt, con
   if (!enabled) return false;
   if (g.Cin != 128 || g.Cout != 128 || g.nty != 3 || g.ntx != 3 || g.KH != 3 || g.KW != 3) return false;
   if (g.iy_mul != 1 || g.ix_mul != 1 || g.oy_mul != 1 || g.ox_mul != 1 || g.oy_add != 0 || g.ox_add != 0) return false;
-  if (g.ky0 != 0 || g.kx0 != 0 || g.kstep != 1 || g.in_affine || g.red_out || bias || g.scale) return false;
-  // (the statistics form is the plain training forward: jspsr_conv2d_forward refuses statistics with bias / ReLU / addend)
+  if (g.ky0 != 0 || g.kx0 != 0 || g.kstep != 1 || g.in_affine || g.red_out) return false;
+  // (the statistics form is the plain training forward: jspsr_conv2d_forward refuses statistics with bias / scale / ReLU / addend)
+  if (bias && !aligned4(bias)) return false;
   if (g.in_cstride % 8 || g.in_coff % 8 || g.out_cstride % 8 || g.out_coff % 8) return false;
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;
@@ -647,7 +666,7 @@ bool conv128_resident_ok(const ConvGeom& g, const void* in, const void* wgt, con
   return tiles >= min_tiles && tiles < 0x7fffffffLL;
 }
 
-int launch_conv128_resident(const void* in, const void* wgt, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
+int launch_conv128_resident(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s) {
   const int ntiles = g.B * ((g.MH + Q_TH - 1) / Q_TH) * ((g.MW + Q_TW - 1) / Q_TW);
   static int ncu = 0;
   if (!ncu) {
@@ -661,12 +680,15 @@ int launch_conv128_resident(const void* in, const void* wgt, void* out, float* s
   if (trace)
     fprintf(stderr, "K2q sign %d B %d %dx%d in pitch %d off %d out pitch %d off %d addend %d (pitch %d) relu %d stats %d in %p out %p\n", g.sign, g.B,
             g.MH, g.MW, g.in_cstride, g.in_coff, g.out_cstride, g.out_coff, g.addend != nullptr, g.add_cstride, g.relu, stats != nullptr, in, out);
+  const int mode = stats ? 1 : ((bias || g.scale) ? 2 : 0);      // the C ABI refuses statistics together with bias / scale
   if (g.sign > 0) {
-    if (stats) launch_k2q<1, 1>(in, wgt, out, stats, g, ntiles, grid, s);
-    else launch_k2q<1, 0>(in, wgt, out, stats, g, ntiles, grid, s);
+    if (mode == 0) launch_k2q<1, 0>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else if (mode == 1) launch_k2q<1, 1>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else launch_k2q<1, 2>(in, wgt, bias, out, stats, g, ntiles, grid, s);
   } else {
-    if (stats) launch_k2q<-1, 1>(in, wgt, out, stats, g, ntiles, grid, s);
-    else launch_k2q<-1, 0>(in, wgt, out, stats, g, ntiles, grid, s);
+    if (mode == 0) launch_k2q<-1, 0>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else if (mode == 1) launch_k2q<-1, 1>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    else launch_k2q<-1, 2>(in, wgt, bias, out, stats, g, ntiles, grid, s);
   }
   return check_launch("conv128_resident");
 }

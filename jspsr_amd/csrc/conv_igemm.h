@@ -98,7 +98,7 @@ int launch_conv64_resident(const void* in, const void* wgt, const float* bias, v
 
 // K2q (conv128.hip): 3x3 128->128 unit-stride bf16 conv / data gradient, the weight matrix resident in one CU's registers
 bool conv128_resident_ok(const ConvGeom& g, const void* in, const void* wgt, const float* bias, const void* out);
-int launch_conv128_resident(const void* in, const void* wgt, void* out, float* stats, const ConvGeom& g, hipStream_t s);
+int launch_conv128_resident(const void* in, const void* wgt, const float* bias, void* out, float* stats, const ConvGeom& g, hipStream_t s);
 
 }  // namespace jspsr
 

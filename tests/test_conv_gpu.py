@@ -232,7 +232,18 @@ def test_conv_resident_128_path(B, H, W):
     assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 2
     assert _relerr(_nchw(out[..., 64:192].float()), F.relu(ref)) < 6e-3
     assert (out[..., :64] == 7.0).all() and (out[..., 192:] == 7.0).all()
-    del wide, out
+    # scale + bias + addend + ReLU (the inference epilogue: BatchNorm folded into the conv), through the same slices
+    scale = torch.rand(128, generator=g) + 0.5
+    bias = torch.randn(128, generator=g)
+    res0 = torch.randn(B, 128, H, W, generator=g).bfloat16().float()
+    out.fill_(7.0)
+    K.conv2d_forward(wide, wp, bias.cuda(), 1, 1, relu=True, out=out, out_coff=64, cin=128, in_coff=32, scale=scale.cuda(),
+                     addend=_nhwc(res0).to(dtype))
+    assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 3
+    ref3 = F.relu((ref * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1)).bfloat16().double() + res0.double())
+    assert _relerr(_nchw(out[..., 64:192].float()), ref3) < 6e-3
+    assert (out[..., :64] == 7.0).all() and (out[..., 192:] == 7.0).all()
+    del wide, out, res0
     # data gradient, plain and with an addend + ReLU
     res = torch.randn(B, 128, H, W, generator=g).bfloat16().float()
     go = torch.randn(B, 128, H, W, generator=g).bfloat16().float()
@@ -242,7 +253,7 @@ def test_conv_resident_128_path(B, H, W):
     dx = K.conv2d_dgrad(_nhwc(go).to(dtype), wpt, (H, W), 1, 1)
     assert _relerr(_nchw(dx.float()), xx.grad) < 6e-3
     dx = K.conv2d_dgrad(_nhwc(go).to(dtype), wpt, (H, W), 1, 1, addend=_nhwc(res).to(dtype), relu=True)
-    assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 4
+    assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 5
     assert _relerr(_nchw(dx.float()), F.relu(xx.grad.bfloat16().double() + res.double())) < 6e-3
 
 

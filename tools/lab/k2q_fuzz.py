@@ -1,5 +1,5 @@
 """Lab: K2q (conv128.hip) on random geometries against torch's fp32 convolution on the GPU -- ragged rasters down to less than
-one tile, batch sizes, channel slices on both sides, addend, ReLU, statistics rows, the dynamic tile queue switched on and off.
+one tile, batch sizes, channel slices on both sides, addend, ReLU, per-channel scale / bias, statistics rows, the dynamic tile queue switched on and off.
 JSPSR_CONV_RESIDENT128_MIN=1 so that every size takes the kernel.  python tools/lab/k2q_fuzz.py [cases] [seed]"""
 import os
 import random
@@ -46,13 +46,22 @@ def main():
             y, st = K.conv2d_forward(xw, wp, None, 1, 1, stats=True, cin=128, in_coff=ic)
             out = torch.full((B, H, W, op), 3.0, dtype=torch.bfloat16, device="cuda")
             K.conv2d_forward(xw, wp, None, 1, 1, relu=relu, out=out, out_coff=oc, cin=128, in_coff=ic)
+            # affine form: [relu]((acc * scale + bias) rounded to bf16 + addend)
+            aff = rnd.random() < 0.5
+            scale = (torch.rand(128, device="cuda", generator=g) + 0.5) if aff and rnd.random() < 0.7 else None
+            bias = torch.randn(128, device="cuda", generator=g) if aff and (scale is None or rnd.random() < 0.7) else None
+            res = torch.randn(B, H, W, 128, device="cuda", generator=g).to(torch.bfloat16) if aff and rnd.random() < 0.5 else None
+            n_aff = 0
+            if aff:
+                ya = K.conv2d_forward(xw, wp, bias, 1, 1, relu=relu, cin=128, in_coff=ic, scale=scale, addend=res)
+                n_aff = 1
             go = torch.randn(B, H, W, 128, device="cuda", generator=g).to(torch.bfloat16)
             addend = torch.randn(B, H, W, 128, device="cuda", generator=g).to(torch.bfloat16) if add else None
             dx = K.conv2d_dgrad(go, wpt, (H, W), 1, 1, addend=addend, relu=relu)
             torch.cuda.synchronize()
         finally:
             lib.jspsr_conv_dynamic_queue(-1)
-        assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 3, "not K2q"
+        assert lib.jspsr_launch_count(b"conv128_resident") == n0 + 3 + n_aff, "not K2q"
         ref.backward(go.float().permute(0, 3, 1, 2))
         rd = ref.detach()
         dref = xr.grad.to(torch.bfloat16).float()
@@ -69,13 +78,24 @@ def main():
             "dgrad": rel(dx.float().permute(0, 3, 1, 2), dref),
             "dgrad max": ((dx.float().permute(0, 3, 1, 2) - dref).abs().max() / dref.abs().max().clamp_min(1e-30)).item(),
         }
+        if aff:
+            ra = rd
+            if scale is not None:
+                ra = ra * scale.view(1, -1, 1, 1)
+            if bias is not None:
+                ra = ra + bias.view(1, -1, 1, 1)
+            if res is not None:
+                ra = ra.to(torch.bfloat16).float() + res.float().permute(0, 3, 1, 2)
+            if relu:
+                ra = torch.relu(ra)
+            errs["affine"] = rel(ya.float().permute(0, 3, 1, 2), ra)
         untouched = bool((out[..., :oc] == 3.0).all() and (out[..., oc + 128:] == 3.0).all())
         # statistics rows: each 8x16 tile's own pixels
         rows = st.double().reshape(B, (H + 7) // 8, (W + 15) // 16, 2, 128)
         r8 = F.pad(rd.double(), (0, -W % 16, 0, -H % 8)).reshape(B, 128, (H + 7) // 8, 8, (W + 15) // 16, 16).sum((3, 5)).permute(0, 2, 3, 1)
         a8 = F.pad(rd.double().abs(), (0, -W % 16, 0, -H % 8)).reshape(B, 128, (H + 7) // 8, 8, (W + 15) // 16, 16).sum((3, 5)).permute(0, 2, 3, 1)
         errs["rows"] = ((rows[..., 0, :] - r8).abs().max() / a8.max().clamp_min(1e-30)).item()
-        tol = {"fwd": 6e-3, "fwd max": 2e-2, "sum": 1e-4, "sumsq": 2e-4, "slice": 6e-3, "dgrad": 6e-3, "dgrad max": 2e-2, "rows": 1e-4}
+        tol = {"fwd": 6e-3, "fwd max": 2e-2, "sum": 1e-4, "sumsq": 2e-4, "slice": 6e-3, "dgrad": 6e-3, "dgrad max": 2e-2, "rows": 1e-4, "affine": 6e-3}
         bad = [k for k in errs if not errs[k] <= tol[k]] + ([] if untouched else ["outside the slice"])
         worst = max(worst, errs["fwd"], errs["dgrad"])
         print(f"{case:3d} B{B} {H}x{W} in {ip}@{ic} out {op}@{oc} addend {int(add)} relu {int(relu)} dynq {int(dynq)}: "
