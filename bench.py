@@ -464,10 +464,26 @@ def inference_leg(model, device):
         strips_out = tiling.emulate_sharded_forward(model, scene, world, halo=128)
         c_err = (strips_out - mono).abs().max().item()
         c_rel = ((strips_out - mono).norm() / mono.norm()).item()
-        # bf16: every conv output is bit-identical per pixel whatever the strip; what differs is the ORDER of the gate
-        # statistics' fp32 sums, and a bf16 rounding that lands on the other side (1 ulp = 0.4 %) then travels -- a few 1e-4
-        # on the random-init network of the tests, up to 2e-3 on the partly trained one the bench holds at this point
-        ok = c_err < 2e-5 if model.compute_dtype == torch.float32 else (c_rel < 5e-3 and c_err < 5e-2 * mono.abs().max().item())
+        # fp32: strips and monolithic agree to 2e-5.  bf16: the two runs do not round alike (kernels are chosen by raster size --
+        # a 768-row window and a 1024-row scene do not take the same conv kernels everywhere -- and the gate statistics' fp32
+        # sums come in another order; a bf16 rounding that lands on the other side then travels), by an amount that depends on
+        # the weights the bench holds at this point (3e-3 after 25 training steps, 9e-3 after 5).  The yardstick is therefore
+        # measured, not fixed: the strips may deviate from the fp32 monolithic forward of the same scene no more than 1.5 x what
+        # the bf16 monolithic forward itself deviates from it (+ 1e-3).
+        e_strips = e_mono = None
+        if model.compute_dtype == torch.float32:
+            ok = c_err < 2e-5
+        else:
+            model.compute_dtype = torch.float32
+            try:
+                with torch.no_grad():
+                    mono32 = model(*scene)
+            finally:
+                model.compute_dtype = torch.bfloat16
+            e_strips = ((strips_out - mono32).norm() / mono32.norm()).item()
+            e_mono = ((mono - mono32).norm() / mono32.norm()).item()
+            ok = e_strips <= 1.5 * e_mono + 1e-3
+            del mono32
         del scene, mono, strips_out
     finally:
         model.train(was_training)
@@ -478,7 +494,10 @@ def inference_leg(model, device):
             "value": round(interior / t / 1e6, 2), "computed_value": round(rows * S / t / 1e6, 2), "unit": "Mpixel/s forward per GPU",
             "max_offset_px": round(max(reach), 2), "receptive_radius": tiling.RECEPTIVE_RADIUS,
             "check": {"scene": f"1024x{S}, {world} strips vs monolithic, same storage type", "ok": bool(ok), "max_abs_diff": float(f"{c_err:.3e}"),
-                      "rel_l2": float(f"{c_rel:.3e}"), "bound": "fp32: 2e-5 abs; bf16: rel L2 5e-3 and max |diff| 5e-2 x max |prediction| (reported, never raised)"}}
+                      "rel_l2": float(f"{c_rel:.3e}"),
+                      "rel_l2_vs_fp32_monolithic": None if e_strips is None else {"strips": float(f"{e_strips:.3e}"), "monolithic": float(f"{e_mono:.3e}")},
+                      "bound": "fp32: 2e-5 abs; bf16: the strips' relative L2 distance from the fp32 monolithic forward <= 1.5 x the bf16 "
+                               "monolithic forward's own + 1e-3 (reported, never raised)"}}
 
 
 def graph_leg_child(args):
