@@ -30,7 +30,10 @@
 //   * BatchNorm statistics (training forward): per-channel sums over a lane's four pixels are in-lane adds, the 16 pixel
 //     columns are the 16 lanes of a DPP row (4 row_ror adds per value), the two K-half waves fold through 2 KB of LDS and
 //     one of them writes the tile's row of the partial-statistics buffer one period later.
-// LDS: 2 x 46 080 (patches, at 0 and 65 536) + 4 x 16 384 (inboxes) + 2 048 (statistics fold) + 1 024 (dump) of 163 840 bytes.
+// A third instantiation applies a per-channel scale / bias before the ReLU / addend (inference with the BatchNorm folded into the
+// conv; bias + ReLU convs): 1 KB of LDS table, two ds_read_b128 per eight channels in the epilogue.
+// LDS: 2 x 46 080 (patches, at 0 and 65 536) + 4 x 16 384 (inboxes) + 2 048 (statistics fold) + 1 024 (dump) + 1 024 (scale | bias)
+// of 163 840 bytes.
 // The MFMAs are issued from inline asm ("a" constraints: the register allocator keeps MFMA A/B operands in VGPRs whatever the
 // pressure and spills the rest of the weights to scratch), which also fixes their order against the fragment reads and the
 // DMA pieces; two hazards the compiler does not see inside an asm statement are covered by hand (s_nop after the last MFMA
@@ -86,8 +89,8 @@ constexpr int Q_ROWS4 = 4 * Q_PW * Q_PIXB;                  // four patch rows: 
 #define K2Q_LD_DIST 27    // ... and written to LDS this many reads later (three pieces = 12 registers in flight)
 #endif
 #ifndef K2Q_DMA_EVERY
-#define K2Q_DMA_EVERY 6  // a piece every so many fragment reads (>= 6: the two stages of a piece sit 3 reads apart), from the start of
-#endif                   // the tap loop: the last of the 12 is requested half a tile before the wait for it (4 .. 12 measured equal)
+#define K2Q_DMA_EVERY 6  // a piece every so many fragment reads, from the start of the tap loop: the last of the 12 is requested half a
+#endif                   // tile before the wait for it (4 .. 12 measured equal: profiles/r04_k2q_wave_life.txt)
 constexpr int Q_NK = 144, Q_LAH = K2Q_LA;                   // fragment reads per tile and wave; look-ahead
 
 __device__ __forceinline__ int inbox_off(int wave) { return wave == 0 ? Q_PATCHB : Q_BUF1 + Q_PATCHB + (wave - 1) * Q_XCHB; }
@@ -203,17 +206,14 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
   // offset that fails the descriptor's range check: `buffer_load ... lds` then writes ZEROS for it -- the conv's zero padding.
   // Issued from inline asm without a memory clobber (the bytes land in the OTHER patch buffer, read after the next
   // barrier); M0 is written in the statement that uses it and by nothing else in this file (csrc/check_m0.sh).
-  // (the source offset of a lane is recomputed per piece -- a handful of VALU operations in the shadow of the MFMAs -- rather
-  // than kept in twelve registers; the swizzle term is the same for all pieces of a lane: 16 i = 0 (mod 8))
+  // (the swizzle term is the same for all pieces of a lane: 16 i = 0 (mod 8))
   const int p0lane = 4 * wave + q;
   const unsigned swz16 = (unsigned)((n ^ (2 * (p0lane & 7))) << 4);
-  // Two stages, a few tap-loop steps apart: with ONE wave per SIMD every VALU cycle beyond the ~36 an MFMA group leaves free
-  // is a cycle the matrix pipe idles (measured with in-kernel stamps: the one-piece arithmetic the compiler made of the plain
-  // expression -- two quarter-rate v_mad_u64_u32 and an EXEC-masked block around them -- cost 180 cycles per piece, 2 150 of
-  // a 12 500-cycle tap loop).  24-bit multiplies (full rate), each kept apart from the add behind it by an empty asm, no
-  // branch; the first stage ends in an asm that pins its three results before the next MFMA group.
   // Interior tiles (all but the image border's) take a lane's source offset of piece i from a register and issue the piece in
-  // three instructions; border tiles recompute the coordinates for the range test behind a scalar branch.
+  // three instructions; border tiles recompute the lane's patch coordinates for the range test behind a scalar branch -- with
+  // 24-bit multiplies (full rate), each kept apart from the add behind it by an empty asm (left alone, the compiler makes
+  // quarter-rate v_mad_u64_u32 of them and an EXEC-masked block around those), and no lane branch.  With ONE wave per SIMD
+  // every instruction in the tap loop that is not an MFMA is time the matrix pipe idles.
   unsigned dsrc[Q_NP];
 #pragma unroll
   for (int i = 0; i < Q_NP; ++i) {
@@ -233,7 +233,6 @@ __device__ __forceinline__ void conv128_body(const __bf16* __restrict__ in, cons
     unsigned t2 = __umul24(c.py, g.IW);                        // 10 IW + 18 and the pixel pitch are < 2^24 (conv128_resident_ok)
     asm("" : "+v"(t2));
     c.off = t2 + (unsigned)c.px;
-    asm volatile("" : "+v"(c.py), "+v"(c.px), "+v"(c.off));
     return c;
   };
   auto piece_src = [&](const QSrc& p, const PieceXY& c) __attribute__((always_inline)) {
