@@ -654,6 +654,7 @@ bool conv128_resident_ok(const ConvGeom& g, const void* in, const void* wgt, con
   if (g.ky0 != 0 || g.kx0 != 0 || g.kstep != 1 || g.in_affine || g.red_out) return false;
   // (the statistics form is the plain training forward: jspsr_conv2d_forward refuses statistics with bias / scale / ReLU / addend)
   if (bias && !aligned4(bias)) return false;
+  if (g.sign < 0 && (bias || g.scale)) return false;      // (see launch_conv128_resident)
   if (g.in_cstride % 8 || g.in_coff % 8 || g.out_cstride % 8 || g.out_coff % 8) return false;
   if (!aligned16(in) || !aligned16(wgt) || !aligned16(out)) return false;
   if (g.addend && (!aligned16(g.addend) || g.add_cstride % 8)) return false;
@@ -685,9 +686,10 @@ int launch_conv128_resident(const void* in, const void* wgt, const float* bias, 
     else if (mode == 1) launch_k2q<1, 1>(in, wgt, bias, out, stats, g, ntiles, grid, s);
     else launch_k2q<1, 2>(in, wgt, bias, out, stats, g, ntiles, grid, s);
   } else {
-    if (mode == 0) launch_k2q<-1, 0>(in, wgt, bias, out, stats, g, ntiles, grid, s);
-    else if (mode == 1) launch_k2q<-1, 1>(in, wgt, bias, out, stats, g, ntiles, grid, s);
-    else launch_k2q<-1, 2>(in, wgt, bias, out, stats, g, ntiles, grid, s);
+    // the reversed walk exists in the plain form only: a data gradient has no statistics, and conv128_resident_ok leaves the
+    // transposed convs with a bias / scale (none of this shape in the models) to the patch kernel -- four instantiations, not six
+    if (mode != 0) return fail(JSPSR_EINVAL, "conv128_resident: the reversed walk has no statistics / affine form");
+    launch_k2q<-1, 0>(in, wgt, bias, out, stats, g, ntiles, grid, s);
   }
   return check_launch("conv128_resident");
 }
